@@ -1,0 +1,129 @@
+/*
+ * smrt_hip.h -- C ABI of the MI355X (gfx950) VAE train-and-generate library.
+ *
+ * The reference (tgsmith61591/smrt) has no FFI: its arithmetic leaves Python at four
+ * tf.Session.run call sites.  Each entry point below names the call site it replaces
+ * (paths relative to the reference root).  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - return 0 on success, negative on error; smrt_last_error() gives the message (thread-local).
+ *   - "dev" pointers are device memory on the handle's GPU, 16-byte aligned, fp32 row-major.
+ *     Input matrices carry a leading dimension (row stride, in floats) that must be a
+ *     multiple of 4; pad columns are never read as data and never written.
+ *   - "host" pointers are ordinary host memory.
+ *   - a handle is bound to one device and one stream; not thread-safe per handle, independent
+ *     handles may be driven from different host threads (one per-class VAE job per GPU).
+ *   - every call returns after its work on the handle's stream has completed unless it says
+ *     "async".
+ *
+ * Flat parameter order ("ABI order", used by set/get_params, get_opt_state and gradients):
+ *   for each dense layer in [enc_1 .. enc_L, z_mean head, z_log_sigma head, dec_1 .. dec_{L+1}]
+ *   (smrt/autoencode/layer.py:292-340): W[fan_in][fan_out] row-major, then b[fan_out].
+ */
+#ifndef SMRT_HIP_H
+#define SMRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smrt_vae smrt_vae;
+
+/* smrt/autoencode/autoencoder.py:28-34 (PERMITTED_ACTIVATIONS) */
+enum { SMRT_ACT_ELU = 0, SMRT_ACT_IDENTITY = 1, SMRT_ACT_RELU = 2, SMRT_ACT_SIGMOID = 3, SMRT_ACT_TANH = 4 };
+/* smrt/autoencode/autoencoder.py:38-48 (PERMITTED_OPTIMIZERS); 'momentum' and 'adagrad-da' cannot be
+ * constructed the way the reference calls them (base.py:138,141) and have no code here. */
+enum { SMRT_OPT_SGD = 0, SMRT_OPT_RMSPROP = 1, SMRT_OPT_ADAM = 2, SMRT_OPT_ADAGRAD = 3,
+       SMRT_OPT_ADADELTA = 4, SMRT_OPT_PROXIMAL_SGD = 5, SMRT_OPT_PROXIMAL_ADAGRAD = 6 };
+
+#define SMRT_MAX_HIDDEN 6
+
+typedef struct smrt_vae_cfg {
+    int32_t  n_features;                 /* D */
+    int32_t  n_hidden_layers;            /* L, 1..SMRT_MAX_HIDDEN */
+    int32_t  hidden[SMRT_MAX_HIDDEN];    /* h_1..h_L */
+    int32_t  n_latent;                   /* Z (already resolved from a float, layer.py:254-257) */
+    int32_t  activation;                 /* SMRT_ACT_*; last decoder layer is always sigmoid (layer.py:333-338) */
+    int32_t  optimizer;                  /* SMRT_OPT_* */
+    float    learning_rate;
+    float    l2_penalty;                 /* < 0 : no regularisation (l2_penalty=None, base.py:128) */
+    int32_t  clip;                       /* base.py:137 */
+    float    gclip_min, gclip_max;       /* base.py:144 */
+    float    bce_lo, bce_hi;             /* float32(eps), float32(1-eps): _ae_utils.py:31 */
+    float    dropout_keep;               /* (0,1]; dropout acts on the WEIGHTS, layer.py:365 */
+    uint64_t seed;                       /* Philox key for epsilon / dropout / fast generate */
+    int32_t  max_batch;                  /* rows per training step the workspace is sized for */
+} smrt_vae_cfg;
+
+/* Replaces graph construction + tf.global_variables_initializer (autoencoder.py:439-486, base.py:185-190).
+ * Weights start at zero; the host initialiser uploads them with smrt_vae_set_params. */
+int  smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out);
+/* Replaces Session.close (base.py:115-121). */
+void smrt_vae_destroy(smrt_vae* h);
+
+/* Number of floats in the flat ABI-order parameter vector. */
+int64_t smrt_vae_param_count(const smrt_vae* h);
+/* tf.Variable initial values / a checkpoint (layer.py:417,464); resets nothing else. host -> device. */
+int  smrt_vae_set_params(smrt_vae* h, const float* host_flat, int64_t n);
+int  smrt_vae_get_params(smrt_vae* h, float* host_flat, int64_t n);
+/* Optimizer slots in ABI order; slot 0/1 = (rms, momentum) | (m, v) | (accumulator, -) | (accum, accum_update).
+ * Also resets/reads the step counter (Adam's beta powers follow it). */
+int  smrt_vae_get_opt_state(smrt_vae* h, int slot, float* host_flat, int64_t n);
+int  smrt_vae_reset_opt_state(smrt_vae* h);
+int64_t smrt_vae_step_count(const smrt_vae* h);
+
+/* Inject dropout keep-masks (0/1 floats, ABI order, bias entries ignored) for the following steps;
+ * NULL returns to the Philox stream.  Parity hook for tf.nn.dropout (layer.py:365). */
+int  smrt_vae_set_dropout_masks(smrt_vae* h, const float* host_flat_or_null, int64_t n);
+
+/* One sess.run([optimizer, cost]) (base.py:215-217): forward, loss, backward, L2, clip, update.
+ *   X_dev       [rows][ldx] training rows (ldx % 4 == 0), rows <= max_batch
+ *   eps_dev     [rows][n_latent] contiguous epsilon to inject, or NULL for the Philox stream
+ *   cost_host   the step's cost (pre-update weights), autoencoder.py:479-480
+ *   grads_host  optional: d cost / d variables BEFORE clipping, ABI order (tf.gradients, base.py:142) */
+int  smrt_vae_train_step(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t rows,
+                         const float* eps_dev, float* cost_host, float* grads_host);
+
+/* The whole _train loop (base.py:198-245) on device: contiguous unshuffled batches with a ragged
+ * tail, n_epochs passes, cost of the LAST batch per epoch, optional early stopping
+ * |last - c| <= min_change.  One host sync per epoch.
+ *   epoch_cost_host[n_epochs], epoch_ms_host[n_epochs] (hipEvent time per epoch), *epochs_done. */
+int  smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n_rows, int32_t batch_size,
+                           int32_t n_epochs, int32_t early_stopping, float min_change,
+                           float* epoch_cost_host, float* epoch_ms_host, int32_t* epochs_done);
+
+/* Data-parallel halves of a step (no reference counterpart): grad_step leaves
+ * [internal-layout gradient sums | sum of row losses] scaled by 1/global_rows in grads_dev
+ * (smrt_vae_dp_count floats) so ranks can all-reduce(SUM) it; apply_grads adds L2, clips, updates.
+ *   row0_global: index of this shard's first row inside the global batch (epsilon is drawn per global row). */
+int64_t smrt_vae_dp_count(const smrt_vae* h);
+int  smrt_vae_grad_step(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t rows, int64_t global_rows,
+                        int64_t row0_global, const float* eps_dev, float* grads_dev);
+int  smrt_vae_apply_grads(smrt_vae* h, const float* grads_dev, float* cost_host);
+
+/* sess.run([z_mean_, z_log_sigma_], {X}) (autoencoder.py:500).  mu/ls are [n][n_latent] contiguous. */
+int  smrt_vae_encode(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n, float* mu_dev, float* logsig_dev);
+/* sess.run(decode, {z_: Z}) (autoencoder.py:517).  Z_dev [n][ldz], out_dev [n][ldo]. */
+int  smrt_vae_decode(smrt_vae* h, const float* Z_dev, int64_t ldz, int64_t n, float* out_dev, int64_t ldo);
+/* Fast generate (no reference counterpart for the RNG): z = loc + scale * N(0,1) from the handle's Philox
+ * stream at element offset philox_offset, then decode.  The exact-compat path of generate()
+ * (autoencoder.py:571, numpy RandomState draws) is host z + smrt_vae_decode. */
+int  smrt_vae_generate(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc, float scale,
+                       float* out_dev, int64_t ldo);
+
+/* Debug/parity: the epsilon the kernels would draw for training step `step`, rows [row0, row0+rows). */
+int  smrt_vae_sample_eps(smrt_vae* h, int64_t step, int64_t row0, int32_t rows, float* eps_dev);
+
+/* Timing of the dominant kernels of the most recent train_epochs call (hipEvent, ms). */
+int  smrt_vae_last_epoch_launches(const smrt_vae* h);
+
+const char* smrt_last_error(void);
+const char* smrt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMRT_HIP_H */

@@ -1,0 +1,298 @@
+"""ctypes binding of ``include/smrt_hip.h`` (``smrt_amd/_lib/libsmrt_hip.so``).
+
+PyTorch-ROCm is used only to own device memory and hand ``data_ptr()`` across; every
+number is produced by the HIP library.  There is NO CPU fallback: a missing library or
+a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libsmrt_hip.so")
+_lib = None
+
+MAX_HIDDEN = 6
+
+ACTIVATION_IDS = {"elu": 0, "identity": 1, "relu": 2, "sigmoid": 3, "tanh": 4}
+OPTIMIZER_IDS = {"sgd": 0, "rms_prop": 1, "adam": 2, "adagrad": 3, "adadelta": 4,
+                 "proximal-sgd": 5, "proximal-adagrad": 6}
+
+EXPORTS = [
+    "smrt_vae_create", "smrt_vae_destroy", "smrt_vae_param_count", "smrt_vae_set_params",
+    "smrt_vae_get_params", "smrt_vae_get_opt_state", "smrt_vae_reset_opt_state", "smrt_vae_step_count",
+    "smrt_vae_set_dropout_masks", "smrt_vae_train_step", "smrt_vae_train_epochs", "smrt_vae_dp_count",
+    "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_encode", "smrt_vae_decode",
+    "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches",
+    "smrt_last_error", "smrt_version",
+]
+
+
+class VaeCfg(C.Structure):
+    _fields_ = [
+        ("n_features", C.c_int32), ("n_hidden_layers", C.c_int32), ("hidden", C.c_int32 * MAX_HIDDEN),
+        ("n_latent", C.c_int32), ("activation", C.c_int32), ("optimizer", C.c_int32),
+        ("learning_rate", C.c_float), ("l2_penalty", C.c_float), ("clip", C.c_int32),
+        ("gclip_min", C.c_float), ("gclip_max", C.c_float), ("bce_lo", C.c_float), ("bce_hi", C.c_float),
+        ("dropout_keep", C.c_float), ("seed", C.c_uint64), ("max_batch", C.c_int32),
+    ]
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HipLibraryError(
+            "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C smrt_amd/csrc`. There is no CPU fallback." % _LIB_PATH)
+    lib = C.CDLL(_LIB_PATH)
+    vp, f32p, i64, i32 = C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.c_int32
+    lib.smrt_last_error.restype = C.c_char_p
+    lib.smrt_version.restype = C.c_char_p
+    lib.smrt_vae_create.argtypes = [C.POINTER(VaeCfg), C.c_int, C.POINTER(vp)]
+    lib.smrt_vae_destroy.argtypes = [vp]
+    lib.smrt_vae_destroy.restype = None
+    lib.smrt_vae_param_count.argtypes = [vp]; lib.smrt_vae_param_count.restype = i64
+    lib.smrt_vae_dp_count.argtypes = [vp]; lib.smrt_vae_dp_count.restype = i64
+    lib.smrt_vae_step_count.argtypes = [vp]; lib.smrt_vae_step_count.restype = i64
+    lib.smrt_vae_last_epoch_launches.argtypes = [vp]
+    lib.smrt_vae_set_params.argtypes = [vp, f32p, i64]
+    lib.smrt_vae_get_params.argtypes = [vp, f32p, i64]
+    lib.smrt_vae_get_opt_state.argtypes = [vp, C.c_int, f32p, i64]
+    lib.smrt_vae_reset_opt_state.argtypes = [vp]
+    lib.smrt_vae_set_dropout_masks.argtypes = [vp, f32p, i64]
+    lib.smrt_vae_train_step.argtypes = [vp, vp, i64, i32, vp, f32p, f32p]
+    lib.smrt_vae_train_epochs.argtypes = [vp, vp, i64, i64, i32, i32, i32, C.c_float, f32p, f32p, C.POINTER(i32)]
+    lib.smrt_vae_grad_step.argtypes = [vp, vp, i64, i32, i64, i64, vp, vp]
+    lib.smrt_vae_apply_grads.argtypes = [vp, vp, f32p]
+    lib.smrt_vae_encode.argtypes = [vp, vp, i64, i64, vp, vp]
+    lib.smrt_vae_decode.argtypes = [vp, vp, i64, i64, vp, i64]
+    lib.smrt_vae_generate.argtypes = [vp, i64, C.c_uint64, C.c_float, C.c_float, vp, i64]
+    lib.smrt_vae_sample_eps.argtypes = [vp, i64, i64, i32, vp]
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise HipLibraryError("%s failed (%d): %s" % (what, rc, load().smrt_last_error().decode()))
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise HipLibraryError("no MI355X visible to PyTorch-ROCm; the HIP path has no CPU fallback")
+    return torch
+
+
+def rup4(v):
+    return (int(v) + 3) & ~3
+
+
+def to_device_padded(array, device):
+    """Host [n, d] array -> contiguous fp32 device tensor [n, rup4(d)]; returns (tensor, ld)."""
+    torch = _torch()
+    a = np.ascontiguousarray(array, dtype=np.float32)
+    n, d = a.shape
+    ld = rup4(d)
+    t = torch.zeros((n, ld), dtype=torch.float32, device=device)
+    if n:
+        t[:, :d] = torch.from_numpy(a).to(device)
+    torch.cuda.synchronize(device)
+    return t, ld
+
+
+class VaeHandle(object):
+    """Owns one ``smrt_vae*``.  Methods take/return numpy arrays or torch device tensors."""
+
+    def __init__(self, n_features, hidden, n_latent, activation, optimizer, learning_rate, l2_penalty, clip,
+                 gclip_min, gclip_max, eps, dropout, seed, max_batch, device=0):
+        lib = load()
+        torch = _torch()
+        if len(hidden) > MAX_HIDDEN:
+            raise ValueError("at most %d hidden layers are supported" % MAX_HIDDEN)
+        cfg = VaeCfg()
+        cfg.n_features, cfg.n_hidden_layers, cfg.n_latent = int(n_features), len(hidden), int(n_latent)
+        for i, hdim in enumerate(hidden):
+            cfg.hidden[i] = int(hdim)
+        cfg.activation, cfg.optimizer = ACTIVATION_IDS[activation], OPTIMIZER_IDS[optimizer]
+        cfg.learning_rate = float(learning_rate)
+        cfg.l2_penalty = -1.0 if l2_penalty is None else float(l2_penalty)
+        cfg.clip, cfg.gclip_min, cfg.gclip_max = int(bool(clip)), float(gclip_min), float(gclip_max)
+        # clip bounds become fp32 constants of the graph: float32(1 - 1e-10) == 1.0f
+        cfg.bce_lo, cfg.bce_hi = float(np.float32(eps)), float(np.float32(1.0 - eps))
+        cfg.dropout_keep = float(dropout)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.max_batch = int(max_batch)
+        self.device = torch.device("cuda", int(device))
+        self.n_features, self.n_latent, self.hidden = int(n_features), int(n_latent), list(hidden)
+        self._h = C.c_void_p()
+        _check(lib.smrt_vae_create(C.byref(cfg), int(device), C.byref(self._h)), "smrt_vae_create")
+        self._lib = lib
+        self.n_params = int(lib.smrt_vae_param_count(self._h))
+
+    # -- lifecycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.smrt_vae_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def closed(self):
+        return not self._h.value
+
+    def _live(self):
+        if self.closed:
+            raise HipLibraryError("VAE handle is closed")
+        return self._h
+
+    # -- parameters / optimizer state (flat ABI order)
+    def set_params(self, flat):
+        flat = np.ascontiguousarray(flat, dtype=np.float32)
+        _check(self._lib.smrt_vae_set_params(self._live(), _f32p(flat), flat.size), "smrt_vae_set_params")
+
+    def get_params(self):
+        out = np.empty(self.n_params, dtype=np.float32)
+        _check(self._lib.smrt_vae_get_params(self._live(), _f32p(out), out.size), "smrt_vae_get_params")
+        return out
+
+    def get_opt_state(self, slot):
+        out = np.empty(self.n_params, dtype=np.float32)
+        _check(self._lib.smrt_vae_get_opt_state(self._live(), int(slot), _f32p(out), out.size), "smrt_vae_get_opt_state")
+        return out
+
+    def reset_opt_state(self):
+        _check(self._lib.smrt_vae_reset_opt_state(self._live()), "smrt_vae_reset_opt_state")
+
+    def set_dropout_masks(self, flat_or_none):
+        if flat_or_none is None:
+            _check(self._lib.smrt_vae_set_dropout_masks(self._live(), None, 0), "smrt_vae_set_dropout_masks")
+            return
+        flat = np.ascontiguousarray(flat_or_none, dtype=np.float32)
+        _check(self._lib.smrt_vae_set_dropout_masks(self._live(), _f32p(flat), flat.size), "smrt_vae_set_dropout_masks")
+
+    @property
+    def step_count(self):
+        return int(self._lib.smrt_vae_step_count(self._live()))
+
+    # -- training
+    def _as_dev(self, X):
+        """numpy [n,d] or (tensor, ld) -> (tensor, ld) on this handle's device."""
+        if isinstance(X, tuple):
+            return X
+        return to_device_padded(X, self.device)
+
+    def train_step(self, X, eps=None, want_grads=False):
+        torch = _torch()
+        Xt, ldx = self._as_dev(X)
+        rows = Xt.shape[0]
+        eps_ptr, eps_t = None, None
+        if eps is not None:
+            eps_t = torch.from_numpy(np.ascontiguousarray(eps, dtype=np.float32)).to(self.device)
+            assert eps_t.shape == (rows, self.n_latent)
+            eps_ptr = eps_t.data_ptr()
+        torch.cuda.synchronize(self.device)
+        cost = C.c_float()
+        grads = np.empty(self.n_params, dtype=np.float32) if want_grads else None
+        _check(self._lib.smrt_vae_train_step(self._live(), Xt.data_ptr(), ldx, rows, eps_ptr, C.byref(cost),
+                                             _f32p(grads) if want_grads else None), "smrt_vae_train_step")
+        return (np.float32(cost.value), grads) if want_grads else np.float32(cost.value)
+
+    def train_epochs(self, X, batch_size, n_epochs, early_stopping=False, min_change=1e-3):
+        Xt, ldx = self._as_dev(X)
+        n = Xt.shape[0]
+        costs = np.zeros(max(n_epochs, 1), dtype=np.float32)
+        ms = np.zeros(max(n_epochs, 1), dtype=np.float32)
+        done = C.c_int32()
+        _check(self._lib.smrt_vae_train_epochs(self._live(), Xt.data_ptr(), ldx, n, int(batch_size), int(n_epochs),
+                                               int(bool(early_stopping)), float(min_change), _f32p(costs), _f32p(ms),
+                                               C.byref(done)), "smrt_vae_train_epochs")
+        return costs[:done.value].copy(), ms[:done.value].copy()
+
+    # -- data-parallel halves
+    @property
+    def dp_count(self):
+        return int(self._lib.smrt_vae_dp_count(self._live()))
+
+    def grad_step(self, X, global_rows, row0_global, grads_tensor, eps=None):
+        torch = _torch()
+        Xt, ldx = self._as_dev(X)
+        eps_ptr, eps_t = None, None
+        if eps is not None:
+            eps_t = torch.from_numpy(np.ascontiguousarray(eps, dtype=np.float32)).to(self.device)
+            eps_ptr = eps_t.data_ptr()
+        torch.cuda.synchronize(self.device)
+        _check(self._lib.smrt_vae_grad_step(self._live(), Xt.data_ptr(), ldx, Xt.shape[0], int(global_rows),
+                                            int(row0_global), eps_ptr, grads_tensor.data_ptr()), "smrt_vae_grad_step")
+
+    def apply_grads(self, grads_tensor):
+        _torch().cuda.synchronize(self.device)
+        cost = C.c_float()
+        _check(self._lib.smrt_vae_apply_grads(self._live(), grads_tensor.data_ptr(), C.byref(cost)), "smrt_vae_apply_grads")
+        return np.float32(cost.value)
+
+    # -- inference
+    def encode(self, X, to_host=True):
+        torch = _torch()
+        Xt, ldx = self._as_dev(X)
+        n = Xt.shape[0]
+        mu = torch.empty((n, self.n_latent), dtype=torch.float32, device=self.device)
+        ls = torch.empty((n, self.n_latent), dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        if n:
+            _check(self._lib.smrt_vae_encode(self._live(), Xt.data_ptr(), ldx, n, mu.data_ptr(), ls.data_ptr()),
+                   "smrt_vae_encode")
+        return (mu.cpu().numpy(), ls.cpu().numpy()) if to_host else (mu, ls)
+
+    def decode(self, Z, to_host=True):
+        torch = _torch()
+        Zt, ldz = self._as_dev(Z)
+        n = Zt.shape[0]
+        out = torch.empty((n, self.n_features), dtype=torch.float32, device=self.device) \
+            if self.n_features % 4 == 0 else torch.empty((n, rup4(self.n_features)), dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        if n:
+            _check(self._lib.smrt_vae_decode(self._live(), Zt.data_ptr(), ldz, n, out.data_ptr(), out.shape[1]),
+                   "smrt_vae_decode")
+        out = out[:, :self.n_features]
+        return out.cpu().numpy() if to_host else out
+
+    def generate(self, n, philox_offset=0, loc=0.0, scale=1.0, to_host=True):
+        torch = _torch()
+        out = torch.empty((n, rup4(self.n_features)), dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        if n:
+            _check(self._lib.smrt_vae_generate(self._live(), n, int(philox_offset), float(loc), float(scale),
+                                               out.data_ptr(), out.shape[1]), "smrt_vae_generate")
+        out = out[:, :self.n_features]
+        return out.cpu().numpy() if to_host else out
+
+    def sample_eps(self, step, row0, rows):
+        torch = _torch()
+        out = torch.empty((rows, self.n_latent), dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        _check(self._lib.smrt_vae_sample_eps(self._live(), int(step), int(row0), int(rows), out.data_ptr()),
+               "smrt_vae_sample_eps")
+        return out.cpu().numpy()

@@ -1,0 +1,50 @@
+"""Input validation shared by the balancers (reference: smrt/balance/base.py:15-64)."""
+from __future__ import annotations
+
+import numpy as np
+from sklearn.utils import column_or_1d
+from sklearn.utils.multiclass import type_of_target
+from sklearn.utils.validation import check_array
+
+from ..utils import NPDTYPE, validate_float
+
+__all__ = ["MAX_N_CLASSES", "MIN_N_SAMPLES", "validate_X_y_ratio_classes"]
+
+MAX_N_CLASSES = 100     # most distinct labels a balancer accepts
+MIN_N_SAMPLES = 2       # fewest rows any class may have
+
+
+def validate_X_y_ratio_classes(X, y, ratio):
+    """Check inputs and derive the class bookkeeping every balancer needs.
+
+    Returns ``(X, y, n_classes, present_classes, counts, majority_label, target_count)`` where ``X`` is a
+    fresh fp64 copy, ``present_classes``/``counts`` come from ``np.unique`` (sorted labels), the majority
+    is the FIRST class with the largest count and ``target_count = max(int(ratio * majority_count), 1)``.
+    Raises ``ValueError`` for a ratio outside (0, 1], a target that is not binary/multiclass, more than
+    ``MAX_N_CLASSES`` labels, or a class with fewer than ``MIN_N_SAMPLES`` rows.
+    """
+    validate_float(ratio, "balance_ratio")
+    X = check_array(X, accept_sparse=False, dtype=NPDTYPE, ensure_2d=True, copy=True)
+    y = column_or_1d(check_array(y, accept_sparse=False, ensure_2d=False, dtype=None), warn=False)
+
+    kind = type_of_target(y)
+    if kind not in ("binary", "multiclass"):
+        raise ValueError("balancers only support (binary, multiclass) targets, but got %r" % kind)
+
+    present_classes, counts = np.unique(y, return_counts=True)
+    n_classes = len(present_classes)
+    if n_classes > MAX_N_CLASSES:
+        raise ValueError("balancers currently only support a maximum of %i unique class labels, but %i were "
+                         "identified." % (MAX_N_CLASSES, n_classes))
+
+    top = int(np.argmax(counts))
+    majority_label, majority_count = present_classes[top], counts[top]
+    target_count = max(int(ratio * majority_count), 1)
+
+    if counts.min() < MIN_N_SAMPLES:
+        raise ValueError("All label counts must be >= %i" % MIN_N_SAMPLES)
+    return X, y, n_classes, present_classes, counts, majority_label, target_count
+
+
+# the reference spells it with a leading underscore (smrt/balance/base.py:19)
+_validate_X_y_ratio_classes = validate_X_y_ratio_classes

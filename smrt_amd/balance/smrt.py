@@ -1,0 +1,174 @@
+"""``smrt_balance`` -- per-minority-class VAE fit + synthesis on MI355X.
+
+Drop-in for the reference function (smrt/balance/smrt.py:22-250): same signature, same return
+values, same consumption order of the ONE shared numpy stream (per class: ``choice`` when
+``gen_from_samples``, then the latent ``normal`` draw; finally the shuffle ``permutation``).
+
+What is different under the hood:
+  * every VAE trains and generates through the HIP library (``smrt_amd.autoencode``);
+  * the output slab is allocated once and each class writes its block in place (the reference
+    re-copies the whole matrix per class, smrt.py:237);
+  * under ``torch.distributed`` (one process per GPU) the independent per-class jobs are sharded
+    across ranks, longest job first, with no collective on the data path; the finished blocks are
+    exchanged once at the end.  The result is identical for any world size because ranks that do
+    not own a class still advance the shared stream by that class's draws.
+  * the reference masks the original ``X`` with a label vector it has already extended
+    (smrt.py:207,238), which numpy >= 1.13 rejects once a second class needs synthesis; the mask
+    here is over the original labels (what numpy 1.12 computed).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from ..autoencode import VariationalAutoEncoder
+from ..autoencode.topography import resolve_latent
+from ..utils import DEFAULT_SEED, get_random_state
+from .base import validate_X_y_ratio_classes
+
+__all__ = ["smrt_balance", "plan_class_jobs"]
+
+
+def _dist():
+    """(rank, world, module) when torch.distributed is initialised, else (0, 1, None)."""
+    try:
+        import torch.distributed as dist
+    except Exception:       # pragma: no cover
+        return 0, 1, None
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size(), dist
+    return 0, 1, None
+
+
+def plan_class_jobs(costs, world):
+    """Greedy longest-job-first assignment of jobs to ``world`` ranks; returns owner per job.
+
+    Deterministic (ties broken by job order, then by lowest rank) so every rank computes the same plan.
+    """
+    owners = [0] * len(costs)
+    load = [0.0] * world
+    for j in sorted(range(len(costs)), key=lambda k: (-costs[k], k)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        owners[j] = r
+        load[r] += costs[j]
+    return owners
+
+
+def _exchange_block(dist, block, shape, src):
+    """Broadcast one finished fp32 block from its owner to every rank."""
+    import torch
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    if block is not None:
+        t = torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32)).to(dev)
+    else:
+        t = torch.empty(shape, dtype=torch.float32, device=dev)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, balance_ratio=0.2,
+                 activation_function='sigmoid', learning_rate=0.05, n_epochs=20, batch_size=128, min_change=1e-3,
+                 verbose=0, display_step=5, learning_function='rms_prop', early_stopping=False, bias_strategy='zeros',
+                 random_state=DEFAULT_SEED, layer_type='xavier', dropout=1., l2_penalty=0.0001,
+                 eps=1e-10, gclip_min=-5., gclip_max=5., clip=True, shuffle=True, gen_from_samples=False,
+                 generate_args=None, prefit_estimators=None):
+    """Balance ``(X, y)`` by synthesising minority rows with one variational auto-encoder per class.
+
+    Every class that is not the majority and has fewer than
+    ``target = max(int(balance_ratio * majority_count), 1)`` rows gets a ``VariationalAutoEncoder`` fitted on its
+    rows (or taken from ``prefit_estimators[label]``) and ``target - count`` synthetic rows from
+    ``generate`` (or, with ``gen_from_samples``, ``generate_from_sample`` on rows re-drawn with replacement).
+    Remaining keyword arguments are the ``VariationalAutoEncoder`` constructor arguments;
+    ``generate_args`` (``loc`` / ``scale``) is forwarded to the latent normal draw.
+
+    Returns ``(X_balanced, y_balanced)`` -- fp64 rows, labels in the caller's label space, shuffled by the
+    shared random state unless ``shuffle=False`` -- plus ``{label: estimator or None}`` when
+    ``return_estimators``.
+    """
+    X, y, n_classes, present_classes, counts, majority_label, target_count = \
+        validate_X_y_ratio_classes(X, y, balance_ratio)
+
+    seeded_random_state = get_random_state(random_state)
+    random_state = seeded_random_state.state
+
+    y_codes = np.searchsorted(present_classes, y)         # == LabelEncoder().fit(present_classes).transform(y)
+
+    if generate_args is None:
+        generate_args = dict()
+    if prefit_estimators is None:
+        prefit_estimators = dict()
+    elif not isinstance(prefit_estimators, dict):
+        raise ValueError('if prefit estimators are provided, it must be a dict')
+
+    # ---- plan: which classes need rows, how many, who owns each job
+    n_orig, n_features = X.shape
+    jobs = []                                             # (class code, label, rows in class, rows needed)
+    encoders = dict()
+    for code, label in enumerate(present_classes):
+        if label == majority_label or counts[code] >= target_count:
+            encoders[label] = None
+            continue
+        encoders[label] = None
+        jobs.append((code, label, int(counts[code]), int(target_count - counts[code])))
+
+    rank, world, dist = _dist()
+    owners = plan_class_jobs([n_sub * max(int(n_epochs), 1) + need for _, _, n_sub, need in jobs], world)
+
+    n_total = n_orig + sum(j[3] for j in jobs)
+    X_out = np.empty((n_total, n_features), dtype=np.float64)
+    X_out[:n_orig] = X
+    y_out_codes = np.empty(n_total, dtype=y_codes.dtype)
+    y_out_codes[:n_orig] = y_codes
+
+    # ---- per-class train-then-generate (smrt.py:197-238); class order fixes the stream order
+    blocks, cursor = [], n_orig
+    for j, (code, label, n_sub, need) in enumerate(jobs):
+        mine = owners[j] == rank
+        X_sub = X[y_codes == code, :]
+        encoder = prefit_estimators.get(label, None)
+        fresh = encoder is None
+        synthetic = None
+        if mine:
+            if fresh:
+                encoder = VariationalAutoEncoder(
+                    n_hidden=n_hidden, n_latent_factors=n_latent_factors, activation_function=activation_function,
+                    learning_rate=learning_rate, n_epochs=n_epochs, batch_size=batch_size, min_change=min_change,
+                    verbose=verbose, display_step=display_step, learning_function=learning_function,
+                    early_stopping=early_stopping, bias_strategy=bias_strategy, random_state=seeded_random_state,
+                    layer_type=layer_type, dropout=dropout, l2_penalty=l2_penalty, eps=eps, gclip_min=gclip_min,
+                    gclip_max=gclip_max, clip=clip).fit(X_sub)
+            encoders[label] = encoder
+            if not gen_from_samples:
+                synthetic = encoder.generate(n=need, **generate_args)
+            else:
+                sample_idcs = random_state.choice(np.arange(n_sub), size=need, replace=True)
+                synthetic = encoder.generate_from_sample(X_sub[sample_idcs, :], **generate_args)
+            synthetic = np.asarray(synthetic)
+            X_out[cursor:cursor + need] = synthetic
+        else:
+            # another rank owns this class: consume exactly the draws it makes on the shared stream
+            if gen_from_samples:
+                random_state.choice(np.arange(n_sub), size=need, replace=True)
+            shares_stream = fresh or getattr(encoder, "random_state_", None) is seeded_random_state
+            if shares_stream:
+                z_dim = resolve_latent(n_latent_factors, n_features) if fresh else int(encoder.n_latent_factors)
+                random_state.normal(size=(need, z_dim))
+        blocks.append((cursor, need, owners[j], synthetic))
+        y_out_codes[cursor:cursor + need] = code
+        cursor += need
+
+    if world > 1:
+        for start, need, owner, synthetic in blocks:
+            got = _exchange_block(dist, synthetic, (need, n_features), owner)
+            if owner != rank:
+                X_out[start:start + need] = got
+
+    y_out = present_classes[y_out_codes]                  # back to the caller's label space (smrt.py:241)
+
+    if shuffle:
+        output_order = random_state.permutation(np.arange(n_total))
+        X_out, y_out = X_out[output_order, :], y_out[output_order]
+
+    if return_estimators:
+        return X_out, y_out, encoders
+    return X_out, y_out

@@ -1,0 +1,694 @@
+// C ABI (include/smrt_hip.h): handle management, workspace, step scheduling.
+#include "../../include/smrt_hip.h"
+#include "vae_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace smrt;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& m) { g_err = m; return code; }
+
+#define HIPC(expr)                                                                              \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail(-2, std::string(#expr) + ": " + hipGetErrorString(e__));                \
+    } while (0)
+
+static inline int rup4(int v) { return (v + 3) & ~3; }
+
+struct LayerI { int fi, fo, ld; long off; int act; int l2; };
+
+struct smrt_vae {
+    smrt_vae_cfg cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int L = 0, NL = 0, Z = 0, D = 0;
+    LayerI lay[MAX_LAYERS];
+    long P_int = 0, P_abi = 0;
+    int maxld = 0;
+    bool has_drop = false, has_l2 = false, masks_injected = false;
+
+    float *W = nullptr, *Wd = nullptr, *mask = nullptr, *s0 = nullptr, *s1 = nullptr;
+    float *G = nullptr, *gtmp = nullptr;
+    int g_splits_cap = 0;
+    DevState* st = nullptr;
+
+    int cap_rows = 0;
+    float* out[MAX_LAYERS] = {nullptr};
+    float* dpre[MAX_LAYERS] = {nullptr};
+    float *Zb = nullptr, *Eb = nullptr;
+    float *bce_p = nullptr, *kl_p = nullptr, *l2_p = nullptr;
+    int n_l2 = 0;
+    float* cost_dev = nullptr; long cost_cap = 0;
+    float* cost_pin = nullptr; long cost_pin_cap = 0;
+
+    long icap = 0;
+    float* ibuf[2] = {nullptr, nullptr};
+    float* izb = nullptr;
+
+    int64_t steps = 0;
+    int last_epoch_launches = 0;
+    int use_graph = 1;
+    std::vector<hipEvent_t> events;
+};
+
+// ------------------------------------------------------------------ layout helpers
+static void build_layers(smrt_vae* h) {
+    const smrt_vae_cfg& c = h->cfg;
+    h->L = c.n_hidden_layers; h->Z = c.n_latent; h->D = c.n_features;
+    h->NL = 2 * h->L + 2;
+    std::vector<int> w(1, c.n_features);
+    for (int i = 0; i < h->L; ++i) w.push_back(c.hidden[i]);
+    int li = 0; long off = 0, pabi = 0; int maxld = rup4(c.n_features);
+    auto add = [&](int fi, int fo, int act, int l2) {
+        LayerI& y = h->lay[li++];
+        y.fi = fi; y.fo = fo; y.ld = rup4(fo); y.off = off; y.act = act; y.l2 = l2;
+        off += (long)(fi + 1) * y.ld;
+        maxld = std::max(maxld, y.ld);
+    };
+    for (int i = 0; i < h->L; ++i) { add(w[i], w[i + 1], c.activation, 1); pabi += (long)w[i] * w[i + 1] + w[i + 1]; }
+    add(w[h->L], 2 * h->Z, c.activation, 0);          // fused heads: never regularised (layer.py:96)
+    pabi += 2 * ((long)w[h->L] * h->Z + h->Z);
+    add(h->Z, w[h->L], c.activation, 1); pabi += (long)h->Z * w[h->L] + w[h->L];
+    for (int i = h->L; i >= 1; --i) {
+        const int act = (i == 1) ? SMRT_ACT_SIGMOID : c.activation;       // layer.py:333-338
+        add(w[i], w[i - 1], act, 1); pabi += (long)w[i] * w[i - 1] + w[i - 1];
+    }
+    h->P_int = off; h->P_abi = pabi; h->maxld = std::max(maxld, rup4(h->Z));
+}
+
+// ABI flat <-> internal flat (host side).  to_internal=true: abi -> internal.
+static void convert(const smrt_vae* h, float* abi, float* internal, bool to_internal) {
+    long o = 0;
+    auto plain = [&](const LayerI& y) {
+        for (int r = 0; r <= y.fi; ++r)
+            for (int c = 0; c < y.fo; ++c) {
+                float& a = abi[o + (long)r * y.fo + c];
+                float& b = internal[y.off + (long)r * y.ld + c];
+                if (to_internal) b = a; else a = b;
+            }
+        o += (long)(y.fi + 1) * y.fo;
+    };
+    for (int l = 0; l < h->L; ++l) plain(h->lay[l]);
+    {
+        const LayerI& y = h->lay[h->L]; const int Z = h->Z;
+        for (int half = 0; half < 2; ++half) {
+            for (int r = 0; r <= y.fi; ++r)
+                for (int c = 0; c < Z; ++c) {
+                    float& a = abi[o + (long)r * Z + c];
+                    float& b = internal[y.off + (long)r * y.ld + half * Z + c];
+                    if (to_internal) b = a; else a = b;
+                }
+            o += (long)(y.fi + 1) * Z;
+        }
+    }
+    for (int l = h->L + 1; l < h->NL; ++l) plain(h->lay[l]);
+}
+
+static void fill_segs(const smrt_vae* h, OptSeg* seg) {
+    long abi_w = 0;
+    for (int l = 0; l < h->NL; ++l) {
+        const LayerI& y = h->lay[l];
+        OptSeg& s = seg[l];
+        s.start = y.off; s.w_count = (long)y.fi * y.ld; s.total = (long)(y.fi + 1) * y.ld;
+        s.ld = y.ld; s.fo = y.fo; s.l2 = y.l2; s.is_heads = (l == h->L);
+        s.abi_w_off = abi_w; s.Z = h->Z; s.hfi = y.fi;
+        abi_w += (long)y.fi * y.fo;
+    }
+}
+
+template <class T> static int dalloc(T** p, size_t n_elems) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    if (n_elems == 0) return 0;
+    hipError_t e = hipMalloc((void**)p, n_elems * sizeof(T));
+    if (e != hipSuccess) return fail(-3, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemset(*p, 0, n_elems * sizeof(T));
+    if (e != hipSuccess) return fail(-3, std::string("hipMemset: ") + hipGetErrorString(e));
+    e = hipDeviceSynchronize();       // the handle's stream is non-blocking: make the zero-fill visible to it
+    if (e != hipSuccess) return fail(-3, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e));
+    return 0;
+}
+#define TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
+
+// ------------------------------------------------------------------ dW tiling / split-K policy
+static int dw_tiles(const smrt_vae* h, int t) {
+    int tot = 0;
+    for (int l = 0; l < h->NL; ++l)
+        tot += ((h->lay[l].fi + 1 + t - 1) / t) * ((h->lay[l].fo + t - 1) / t);
+    return tot;
+}
+static bool dw_big(const smrt_vae* h, int rows) { return rows >= 2048 && dw_tiles(h, 128) >= 48; }
+static int choose_splits(const smrt_vae* h, int rows) {
+    const int T = dw_tiles(h, dw_big(h, rows) ? 128 : 64);
+    int s = (1024 + T - 1) / T;
+    s = std::min(s, (rows + 127) / 128);
+    return std::max(1, std::min(s, 32));
+}
+
+static int ensure_train(smrt_vae* h, int rows) {
+    const int splits = choose_splits(h, rows);
+    if (splits > h->g_splits_cap) {
+        TRY(dalloc(&h->G, (size_t)splits * h->P_int));
+        h->g_splits_cap = splits;
+    }
+    if (rows <= h->cap_rows) return 0;
+    int cap = std::max(rows, (int)h->cfg.max_batch);
+    for (int l = 0; l < h->NL; ++l) {
+        if (l < h->NL - 1) TRY(dalloc(&h->out[l], (size_t)cap * h->lay[l].ld));
+        TRY(dalloc(&h->dpre[l], (size_t)cap * h->lay[l].ld));
+    }
+    TRY(dalloc(&h->Zb, (size_t)cap * rup4(h->Z)));
+    TRY(dalloc(&h->Eb, (size_t)cap * rup4(h->Z)));
+    const int nb = ((cap + 63) / 64) * ((h->D + 63) / 64);
+    TRY(dalloc(&h->bce_p, (size_t)nb));
+    TRY(dalloc(&h->kl_p, (size_t)reparam_blocks(cap, h->Z)));
+    h->cap_rows = cap;
+    return 0;
+}
+
+static int ensure_infer(smrt_vae* h, long rows) {
+    if (rows <= h->icap) return 0;
+    TRY(dalloc(&h->ibuf[0], (size_t)rows * h->maxld));
+    TRY(dalloc(&h->ibuf[1], (size_t)rows * h->maxld));
+    TRY(dalloc(&h->izb, (size_t)rows * rup4(h->Z)));
+    h->icap = rows;
+    return 0;
+}
+
+static int check_mat(const void* p, int64_t ld, int cols, const char* what) {
+    if (!p) return fail(-1, std::string(what) + ": null pointer");
+    if (((uintptr_t)p & 15) != 0) return fail(-1, std::string(what) + ": pointer must be 16-byte aligned");
+    if (ld % 4 != 0 || ld < cols) return fail(-1, std::string(what) + ": leading dimension must be a multiple of 4 and >= columns");
+    return 0;
+}
+
+// ------------------------------------------------------------------ one training step, enqueued async
+struct StepOut { float* cost_slot; float* grad_out; float* dp_out; };
+
+// mode 0: full step (optimizer + finalize).  mode 1: gradients only (data-parallel first half).
+static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float inv_batch, long row0_global,
+                        const float* eps_in, int mode, const StepOut& o) {
+    hipStream_t s = h->stream;
+    const int L = h->L, NL = h->NL, Z = h->Z;
+    const float* Wuse = h->W;
+    int launches = 0;
+    OptSeg segs[MAX_LAYERS];
+    fill_segs(h, segs);
+
+    if (h->has_drop) {
+        DropArgs d{};
+        std::memcpy(d.seg, segs, sizeof(OptSeg) * NL); d.n_seg = NL; d.P = h->P_int;
+        d.W = h->W; d.Wd = h->Wd; d.mask = h->mask; d.st = h->st; d.seed = h->cfg.seed;
+        d.keep = h->cfg.dropout_keep; d.injected = h->masks_injected ? 1 : 0;
+        launch_dropout(s, d); ++launches;
+        Wuse = h->Wd;
+    }
+    auto in_of = [&](int l) -> const float* { return l == 0 ? X : (l == L + 1 ? h->Zb : h->out[l - 1]); };
+    auto ldin_of = [&](int l) -> long { return l == 0 ? ldx : (l == L + 1 ? (long)rup4(Z) : (long)h->lay[l - 1].ld); };
+
+    int n_bce = 0;
+    // ---- forward
+    for (int l = 0; l < NL; ++l) {
+        const LayerI& y = h->lay[l];
+        GemmArgs a{};
+        a.A = in_of(l); a.lda = ldin_of(l);
+        a.B = Wuse + y.off; a.ldb = y.ld; a.bias = h->W + y.off + (long)y.fi * y.ld;
+        a.M = rows; a.N = y.fo; a.K = y.fi; a.act = y.act; a.Z = Z;
+        if (l < NL - 1) {
+            a.C = h->out[l]; a.ldc = y.ld;
+            launch_gemm(s, GEMM_NN, EPI_BIAS_ACT, a); ++launches;
+            if (l == L) {
+                launch_reparam(s, h->out[L], y.ld, eps_in, h->Zb, h->Eb, rup4(Z), rows, Z, h->cfg.seed, h->st,
+                               row0_global, h->kl_p);
+                ++launches;
+            }
+        } else {
+            a.C = h->dpre[l]; a.ldc = y.ld; a.aux = X; a.ldaux = ldx;
+            a.lo = h->cfg.bce_lo; a.hi = h->cfg.bce_hi; a.inv_batch = inv_batch; a.partials = h->bce_p;
+            n_bce = gemm_grid_blocks(GEMM_NN, a);
+            launch_gemm(s, GEMM_NN, EPI_BCE, a); ++launches;
+        }
+    }
+    // ---- backward through the activations
+    for (int l = NL - 1; l >= 1; --l) {
+        const LayerI& y = h->lay[l];
+        GemmArgs a{};
+        a.A = h->dpre[l]; a.lda = y.ld; a.M = rows; a.K = y.fo;
+        a.B = Wuse + y.off; a.ldb = y.ld; a.N = y.fi;
+        a.Z = Z; a.inv_batch = inv_batch;
+        if (l == L + 1) {
+            a.C = h->dpre[L]; a.ldc = h->lay[L].ld; a.aux = h->out[L]; a.ldaux = h->lay[L].ld;
+            a.aux2 = h->Eb; a.ldaux2 = rup4(Z); a.act = h->lay[L].act;
+            launch_gemm(s, GEMM_NT, EPI_LATENT, a);
+        } else {
+            a.C = h->dpre[l - 1]; a.ldc = h->lay[l - 1].ld; a.aux = h->out[l - 1]; a.ldaux = h->lay[l - 1].ld;
+            a.act = h->lay[l - 1].act;
+            launch_gemm(s, GEMM_NT, EPI_ACTGRAD, a);
+        }
+        ++launches;
+    }
+    // ---- all weight/bias gradients in one launch
+    const int splits = std::min(choose_splits(h, rows), h->g_splits_cap);
+    const bool big = dw_big(h, rows);
+    {
+        DwArgs d{};
+        const int t = big ? 128 : 64;
+        int tb = 0;
+        for (int l = 0; l < NL; ++l) {
+            const LayerI& y = h->lay[l];
+            DwLayer& q = d.L[l];
+            q.A = in_of(l); q.lda = ldin_of(l); q.B = h->dpre[l]; q.ldb = y.ld;
+            q.C = h->G + y.off; q.ldc = y.ld; q.fi = y.fi; q.fo = y.fo;
+            q.tiles_n = (y.fo + t - 1) / t; q.tile_begin = tb;
+            tb += ((y.fi + 1 + t - 1) / t) * q.tiles_n;
+        }
+        d.n_layers = NL; d.total_tiles = tb; d.rows = rows; d.splits = splits;
+        d.k_per_split = (((rows + splits - 1) / splits) + 31) & ~31;
+        d.slab_stride = h->P_int;
+        launch_dw(s, d, big); ++launches;
+    }
+    const int n_kl = reparam_blocks(rows, Z);
+    if (mode == 1) {
+        launch_reduce_slabs(s, h->G, splits, h->P_int, h->P_int, o.dp_out); ++launches;
+        FinalizeArgs f{};
+        f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = nullptr; f.n_l2 = 0;
+        f.inv_batch = inv_batch; f.l2 = 0.f; f.loss_sum_out = o.dp_out + h->P_int; f.st = h->st; f.advance = 0;
+        launch_finalize(s, f); ++launches;
+        h->last_epoch_launches = launches;
+        return 0;
+    }
+    // ---- fused reduce + L2 + clip + update, then the scalar cost
+    OptArgs p{};
+    std::memcpy(p.seg, segs, sizeof(OptSeg) * NL); p.n_seg = NL; p.P = h->P_int;
+    p.W = h->W; p.Wd = h->Wd; p.mask = h->mask; p.G = h->G; p.splits = splits; p.slab_stride = h->P_int;
+    p.s0 = h->s0; p.s1 = h->s1; p.grad_out = o.grad_out; p.l2_partials = h->l2_p; p.st = h->st;
+    p.opt = h->cfg.optimizer; p.clip = h->cfg.clip; p.has_drop = h->has_drop; p.has_l2 = h->has_l2;
+    p.lr = h->cfg.learning_rate; p.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
+    p.gmin = h->cfg.gclip_min; p.gmax = h->cfg.gclip_max; p.keep = h->cfg.dropout_keep;
+    launch_optimizer(s, p, nullptr); ++launches;
+    FinalizeArgs f{};
+    f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p; f.n_l2 = h->n_l2;
+    f.inv_batch = inv_batch; f.l2 = p.l2; f.cost_out = o.cost_slot; f.st = h->st; f.advance = 1;
+    launch_finalize(s, f); ++launches;
+    h->last_epoch_launches = launches;
+    return 0;
+}
+
+// ------------------------------------------------------------------ ABI
+extern "C" {
+
+const char* smrt_last_error(void) { return g_err.c_str(); }
+const char* smrt_version(void) { return "smrt-hip 0.1 (gfx950)"; }
+
+int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
+    if (!cfg || !out) return fail(-1, "smrt_vae_create: null argument");
+    if (cfg->n_features < 1 || cfg->n_latent < 1) return fail(-1, "smrt_vae_create: n_features and n_latent must be >= 1");
+    if (cfg->n_hidden_layers < 1 || cfg->n_hidden_layers > SMRT_MAX_HIDDEN)
+        return fail(-1, "smrt_vae_create: n_hidden_layers must be in 1..SMRT_MAX_HIDDEN");
+    for (int i = 0; i < cfg->n_hidden_layers; ++i)
+        if (cfg->hidden[i] < 1) return fail(-1, "smrt_vae_create: hidden widths must be >= 1");
+    if (cfg->activation < 0 || cfg->activation > 4) return fail(-1, "smrt_vae_create: bad activation id");
+    if (cfg->optimizer < 0 || cfg->optimizer > 6) return fail(-1, "smrt_vae_create: bad optimizer id");
+    if (!(cfg->dropout_keep > 0.f && cfg->dropout_keep <= 1.f)) return fail(-1, "smrt_vae_create: dropout_keep must be in (0,1]");
+    if (cfg->max_batch < 1) return fail(-1, "smrt_vae_create: max_batch must be >= 1");
+    int ndev = 0;
+    HIPC(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(-1, "smrt_vae_create: no such device");
+    HIPC(hipSetDevice(device));
+    smrt_vae* h = new smrt_vae();
+    h->cfg = *cfg; h->device = device;
+    build_layers(h);
+    h->has_drop = cfg->dropout_keep < 1.0f;
+    h->has_l2 = cfg->l2_penalty >= 0.f;
+    const char* g = std::getenv("SMRT_HIP_GRAPH");
+    h->use_graph = g ? std::atoi(g) : 1;
+    auto bail = [&](int rc) { smrt_vae_destroy(h); return rc; };
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(-2, "hipStreamCreate failed"));
+    int rc;
+    if ((rc = dalloc(&h->W, (size_t)h->P_int))) return bail(rc);
+    if ((rc = dalloc(&h->s0, (size_t)h->P_int))) return bail(rc);
+    if ((rc = dalloc(&h->s1, (size_t)h->P_int))) return bail(rc);
+    if ((rc = dalloc(&h->gtmp, (size_t)h->P_int + 4))) return bail(rc);
+    if (h->has_drop) {
+        if ((rc = dalloc(&h->Wd, (size_t)h->P_int))) return bail(rc);
+        if ((rc = dalloc(&h->mask, (size_t)h->P_int))) return bail(rc);
+    }
+    h->n_l2 = optimizer_blocks(h->P_int);
+    if ((rc = dalloc(&h->l2_p, (size_t)h->n_l2))) return bail(rc);
+    if ((rc = dalloc(&h->st, 1))) return bail(rc);
+    if ((rc = smrt_vae_reset_opt_state(h))) return bail(rc);
+    if ((rc = ensure_train(h, cfg->max_batch))) return bail(rc);
+    *out = h;
+    return 0;
+}
+
+void smrt_vae_destroy(smrt_vae* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    float** bufs[] = {&h->W, &h->Wd, &h->mask, &h->s0, &h->s1, &h->G, &h->gtmp, &h->Zb, &h->Eb, &h->bce_p, &h->kl_p,
+                      &h->l2_p, &h->cost_dev, &h->ibuf[0], &h->ibuf[1], &h->izb};
+    for (float** b : bufs) if (*b) (void)hipFree(*b);
+    for (int l = 0; l < MAX_LAYERS; ++l) { if (h->out[l]) (void)hipFree(h->out[l]); if (h->dpre[l]) (void)hipFree(h->dpre[l]); }
+    if (h->st) (void)hipFree(h->st);
+    if (h->cost_pin) (void)hipHostFree(h->cost_pin);
+    for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int64_t smrt_vae_param_count(const smrt_vae* h) { return h ? h->P_abi : -1; }
+int64_t smrt_vae_dp_count(const smrt_vae* h) { return h ? h->P_int + 4 : -1; }
+int64_t smrt_vae_step_count(const smrt_vae* h) { return h ? h->steps : -1; }
+int smrt_vae_last_epoch_launches(const smrt_vae* h) { return h ? h->last_epoch_launches : -1; }
+
+int smrt_vae_set_params(smrt_vae* h, const float* host_flat, int64_t n) {
+    if (!h || !host_flat) return fail(-1, "smrt_vae_set_params: null argument");
+    if (n != h->P_abi) return fail(-1, "smrt_vae_set_params: expected " + std::to_string(h->P_abi) + " floats");
+    HIPC(hipSetDevice(h->device));
+    std::vector<float> in(h->P_int, 0.f);
+    convert(h, const_cast<float*>(host_flat), in.data(), true);
+    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipMemcpy(h->W, in.data(), sizeof(float) * h->P_int, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int download_abi(smrt_vae* h, const float* dev, float* host_flat, int64_t n, const char* who) {
+    if (!h || !host_flat) return fail(-1, std::string(who) + ": null argument");
+    if (n != h->P_abi) return fail(-1, std::string(who) + ": expected " + std::to_string(h->P_abi) + " floats");
+    HIPC(hipSetDevice(h->device));
+    std::vector<float> in(h->P_int);
+    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipMemcpy(in.data(), dev, sizeof(float) * h->P_int, hipMemcpyDeviceToHost));
+    convert(h, host_flat, in.data(), false);
+    return 0;
+}
+
+int smrt_vae_get_params(smrt_vae* h, float* host_flat, int64_t n) {
+    return download_abi(h, h ? h->W : nullptr, host_flat, n, "smrt_vae_get_params");
+}
+
+int smrt_vae_get_opt_state(smrt_vae* h, int slot, float* host_flat, int64_t n) {
+    if (slot != 0 && slot != 1) return fail(-1, "smrt_vae_get_opt_state: slot must be 0 or 1");
+    return download_abi(h, h ? (slot ? h->s1 : h->s0) : nullptr, host_flat, n, "smrt_vae_get_opt_state");
+}
+
+int smrt_vae_reset_opt_state(smrt_vae* h) {
+    if (!h) return fail(-1, "smrt_vae_reset_opt_state: null handle");
+    HIPC(hipSetDevice(h->device));
+    HIPC(hipStreamSynchronize(h->stream));
+    float v0 = 0.f;
+    if (h->cfg.optimizer == SMRT_OPT_RMSPROP) v0 = 1.0f;                                  // rms slot starts at one
+    if (h->cfg.optimizer == SMRT_OPT_ADAGRAD || h->cfg.optimizer == SMRT_OPT_PROXIMAL_ADAGRAD) v0 = 0.1f;
+    std::vector<float> a(h->P_int, v0);
+    HIPC(hipMemcpy(h->s0, a.data(), sizeof(float) * h->P_int, hipMemcpyHostToDevice));
+    HIPC(hipMemset(h->s1, 0, sizeof(float) * h->P_int));
+    DevState st{0.9f, 0.999f, 0u, 0u};
+    HIPC(hipMemcpy(h->st, &st, sizeof(st), hipMemcpyHostToDevice));
+    h->steps = 0;
+    return 0;
+}
+
+int smrt_vae_set_dropout_masks(smrt_vae* h, const float* host_flat, int64_t n) {
+    if (!h) return fail(-1, "smrt_vae_set_dropout_masks: null handle");
+    if (!host_flat) { h->masks_injected = false; return 0; }
+    if (!h->has_drop) return fail(-1, "smrt_vae_set_dropout_masks: handle was created with dropout_keep == 1");
+    if (n != h->P_abi) return fail(-1, "smrt_vae_set_dropout_masks: expected " + std::to_string(h->P_abi) + " floats");
+    HIPC(hipSetDevice(h->device));
+    std::vector<float> in(h->P_int, 0.f);
+    convert(h, const_cast<float*>(host_flat), in.data(), true);
+    HIPC(hipStreamSynchronize(h->stream));
+    HIPC(hipMemcpy(h->mask, in.data(), sizeof(float) * h->P_int, hipMemcpyHostToDevice));
+    h->masks_injected = true;
+    return 0;
+}
+
+static int ensure_cost(smrt_vae* h, long n) {
+    if (n > h->cost_cap) { TRY(dalloc(&h->cost_dev, (size_t)n)); h->cost_cap = n; }
+    if (n > h->cost_pin_cap) {
+        if (h->cost_pin) (void)hipHostFree(h->cost_pin);
+        h->cost_pin = nullptr;
+        HIPC(hipHostMalloc((void**)&h->cost_pin, sizeof(float) * n, hipHostMallocDefault));
+        h->cost_pin_cap = n;
+    }
+    return 0;
+}
+
+int smrt_vae_train_step(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t rows, const float* eps_dev,
+                        float* cost_host, float* grads_host) {
+    if (!h) return fail(-1, "smrt_vae_train_step: null handle");
+    if (rows < 1) return fail(-1, "smrt_vae_train_step: rows must be >= 1");
+    TRY(check_mat(X_dev, ldx, h->D, "smrt_vae_train_step: X"));
+    HIPC(hipSetDevice(h->device));
+    TRY(ensure_train(h, rows));
+    TRY(ensure_cost(h, 1));
+    StepOut o{h->cost_dev, grads_host ? h->gtmp : nullptr, nullptr};
+    TRY(enqueue_step(h, X_dev, ldx, rows, 1.0f / (float)rows, 0, eps_dev, 0, o));
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(h->cost_pin, h->cost_dev, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    h->steps += 1;
+    if (cost_host) *cost_host = h->cost_pin[0];
+    if (grads_host) {
+        std::vector<float> in(h->P_int);
+        HIPC(hipMemcpy(in.data(), h->gtmp, sizeof(float) * h->P_int, hipMemcpyDeviceToHost));
+        convert(h, grads_host, in.data(), false);
+    }
+    return 0;
+}
+
+int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n_rows, int32_t batch_size,
+                          int32_t n_epochs, int32_t early_stopping, float min_change,
+                          float* epoch_cost_host, float* epoch_ms_host, int32_t* epochs_done) {
+    if (!h) return fail(-1, "smrt_vae_train_epochs: null handle");
+    if (n_rows < 1 || batch_size < 1 || n_epochs < 0) return fail(-1, "smrt_vae_train_epochs: bad sizes");
+    TRY(check_mat(X_dev, ldx, h->D, "smrt_vae_train_epochs: X"));
+    HIPC(hipSetDevice(h->device));
+    const int bmax = (int)std::min<int64_t>(batch_size, n_rows);
+    TRY(ensure_train(h, bmax));
+    const long nb = (n_rows + batch_size - 1) / batch_size;
+    TRY(ensure_cost(h, std::max<long>(n_epochs, 1) + 1));
+    while ((long)h->events.size() < 2L * std::max(n_epochs, 1)) {
+        hipEvent_t e; HIPC(hipEventCreate(&e)); h->events.push_back(e);
+    }
+    if (epochs_done) *epochs_done = 0;
+    if (n_epochs == 0) return 0;
+
+    // Enqueue one epoch (every contiguous batch, ragged tail last: sklearn gen_batches, base.py:198-199).
+    // The cost of the LAST batch lands in `slot` (base.py:222); other steps write a scratch slot.
+    auto enqueue_epoch = [&](float* slot) -> int {
+        int launches = 0;
+        for (long b = 0; b < nb; ++b) {
+            const long r0 = b * batch_size;
+            const int rows = (int)std::min<long>(batch_size, n_rows - r0);
+            StepOut o{(b == nb - 1) ? slot : h->cost_dev + h->cost_cap - 1, nullptr, nullptr};
+            TRY(enqueue_step(h, X_dev + r0 * ldx, ldx, rows, 1.0f / (float)rows, 0, nullptr, 0, o));
+            launches += h->last_epoch_launches;
+        }
+        h->last_epoch_launches = launches;
+        return 0;
+    };
+
+    // A captured graph replays the identical epoch: every step-dependent scalar (Philox step, Adam powers)
+    // lives in device memory, so only the cost slot differs -> the graph writes slot 0 and a copy node moves it.
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    bool graphed = false;
+    if (h->use_graph && n_epochs > 1) {
+        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc = enqueue_epoch(h->cost_dev);
+            hipError_t e = hipStreamEndCapture(h->stream, &graph);
+            if (rc == 0 && e == hipSuccess && graph &&
+                hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess) graphed = true;
+            else { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); graph = nullptr; if (rc) return rc; }
+        } else (void)hipGetLastError();
+    }
+    int done = 0; float last_cost = 0.f; bool have_last = false; int rc = 0;
+    auto cleanup = [&]() { if (gexec) (void)hipGraphExecDestroy(gexec); if (graph) (void)hipGraphDestroy(graph); };
+    auto run_epoch = [&](int ep) -> int {
+        HIPC(hipEventRecord(h->events[2 * ep], h->stream));
+        if (graphed) HIPC(hipGraphLaunch(gexec, h->stream));
+        else TRY(enqueue_epoch(h->cost_dev));
+        HIPC(hipEventRecord(h->events[2 * ep + 1], h->stream));
+        HIPC(hipMemcpyAsync(h->cost_pin + ep, h->cost_dev, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        return 0;
+    };
+    if (!early_stopping) {
+        for (int ep = 0; ep < n_epochs && rc == 0; ++ep) rc = run_epoch(ep);
+        if (rc) { cleanup(); return rc; }
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { cleanup(); return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e)); }
+        done = n_epochs;
+    } else {
+        for (int ep = 0; ep < n_epochs; ++ep) {
+            rc = run_epoch(ep);
+            if (rc) { cleanup(); return rc; }
+            hipError_t e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { cleanup(); return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e)); }
+            done = ep + 1;
+            const float c = h->cost_pin[ep];
+            if (!have_last) { last_cost = c; have_last = true; }
+            else if (std::fabs(last_cost - c) <= min_change) break;       // base.py:234-238
+            else last_cost = c;
+        }
+    }
+    for (int ep = 0; ep < done; ++ep) {
+        if (epoch_cost_host) epoch_cost_host[ep] = h->cost_pin[ep];
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, h->events[2 * ep], h->events[2 * ep + 1]);
+        if (epoch_ms_host) epoch_ms_host[ep] = ms;
+    }
+    h->steps += (int64_t)done * nb;
+    if (epochs_done) *epochs_done = done;
+    cleanup();
+    return 0;
+}
+
+int smrt_vae_grad_step(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t rows, int64_t global_rows,
+                       int64_t row0_global, const float* eps_dev, float* grads_dev) {
+    if (!h || !grads_dev) return fail(-1, "smrt_vae_grad_step: null argument");
+    if (rows < 1 || global_rows < rows) return fail(-1, "smrt_vae_grad_step: bad row counts");
+    if (h->has_drop) return fail(-1, "smrt_vae_grad_step: dropout < 1 is not supported on the data-parallel path");
+    TRY(check_mat(X_dev, ldx, h->D, "smrt_vae_grad_step: X"));
+    if (((uintptr_t)grads_dev & 15) != 0) return fail(-1, "smrt_vae_grad_step: grads_dev must be 16-byte aligned");
+    HIPC(hipSetDevice(h->device));
+    TRY(ensure_train(h, rows));
+    StepOut o{nullptr, nullptr, grads_dev};
+    TRY(enqueue_step(h, X_dev, ldx, rows, 1.0f / (float)global_rows, row0_global, eps_dev, 1, o));
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int smrt_vae_apply_grads(smrt_vae* h, const float* grads_dev, float* cost_host) {
+    if (!h || !grads_dev) return fail(-1, "smrt_vae_apply_grads: null argument");
+    if (((uintptr_t)grads_dev & 15) != 0) return fail(-1, "smrt_vae_apply_grads: grads_dev must be 16-byte aligned");
+    HIPC(hipSetDevice(h->device));
+    TRY(ensure_cost(h, 1));
+    OptSeg segs[MAX_LAYERS];
+    fill_segs(h, segs);
+    OptArgs p{};
+    std::memcpy(p.seg, segs, sizeof(OptSeg) * h->NL); p.n_seg = h->NL; p.P = h->P_int;
+    p.W = h->W; p.G = grads_dev; p.splits = 1; p.slab_stride = h->P_int;
+    p.s0 = h->s0; p.s1 = h->s1; p.l2_partials = h->l2_p; p.st = h->st;
+    p.opt = h->cfg.optimizer; p.clip = h->cfg.clip; p.has_drop = 0; p.has_l2 = h->has_l2;
+    p.lr = h->cfg.learning_rate; p.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
+    p.gmin = h->cfg.gclip_min; p.gmax = h->cfg.gclip_max; p.keep = 1.f;
+    launch_optimizer(h->stream, p, nullptr);
+    FinalizeArgs f{};
+    f.l2p = h->l2_p; f.n_l2 = h->n_l2; f.presummed = grads_dev + h->P_int; f.l2 = p.l2;
+    f.cost_out = h->cost_dev; f.st = h->st; f.advance = 1;
+    launch_finalize(h->stream, f);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(h->cost_pin, h->cost_dev, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPC(hipStreamSynchronize(h->stream));
+    h->steps += 1;
+    if (cost_host) *cost_host = h->cost_pin[0];
+    return 0;
+}
+
+static const long INFER_CHUNK = 32768;
+
+int smrt_vae_encode(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n, float* mu_dev, float* logsig_dev) {
+    if (!h || !mu_dev || !logsig_dev) return fail(-1, "smrt_vae_encode: null argument");
+    if (n < 0) return fail(-1, "smrt_vae_encode: n must be >= 0");
+    if (n == 0) return 0;
+    TRY(check_mat(X_dev, ldx, h->D, "smrt_vae_encode: X"));
+    HIPC(hipSetDevice(h->device));
+    const long chunk = std::min<long>(n, INFER_CHUNK);
+    TRY(ensure_infer(h, chunk));
+    for (long r0 = 0; r0 < n; r0 += chunk) {
+        const int rows = (int)std::min<long>(chunk, n - r0);
+        const float* in = X_dev + r0 * ldx; long ldin = ldx;
+        for (int l = 0; l <= h->L; ++l) {
+            const LayerI& y = h->lay[l];
+            GemmArgs a{};
+            a.A = in; a.lda = ldin; a.B = h->W + y.off; a.ldb = y.ld; a.bias = h->W + y.off + (long)y.fi * y.ld;
+            a.M = rows; a.N = y.fo; a.K = y.fi; a.act = y.act; a.Z = h->Z;
+            if (l < h->L) {
+                a.C = h->ibuf[l & 1]; a.ldc = y.ld;
+                launch_gemm(h->stream, GEMM_NN, EPI_BIAS_ACT, a);
+                in = a.C; ldin = y.ld;
+            } else {
+                a.C = mu_dev + r0 * h->Z; a.out2 = logsig_dev + r0 * h->Z;
+                launch_gemm(h->stream, GEMM_NN, EPI_HEADS_SPLIT, a);
+            }
+        }
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int decode_chunk(smrt_vae* h, const float* Zin, long ldz, int rows, float* out, long ldo) {
+    const float* in = Zin; long ldin = ldz;
+    for (int l = h->L + 1; l < h->NL; ++l) {
+        const LayerI& y = h->lay[l];
+        GemmArgs a{};
+        a.A = in; a.lda = ldin; a.B = h->W + y.off; a.ldb = y.ld; a.bias = h->W + y.off + (long)y.fi * y.ld;
+        a.M = rows; a.N = y.fo; a.K = y.fi; a.act = y.act; a.Z = h->Z;
+        if (l < h->NL - 1) { a.C = h->ibuf[l & 1]; a.ldc = y.ld; }
+        else               { a.C = out; a.ldc = ldo; }
+        launch_gemm(h->stream, GEMM_NN, EPI_BIAS_ACT, a);
+        in = a.C; ldin = y.ld;
+    }
+    return 0;
+}
+
+int smrt_vae_decode(smrt_vae* h, const float* Z_dev, int64_t ldz, int64_t n, float* out_dev, int64_t ldo) {
+    if (!h || !out_dev) return fail(-1, "smrt_vae_decode: null argument");
+    if (n < 0) return fail(-1, "smrt_vae_decode: n must be >= 0");
+    if (n == 0) return 0;
+    TRY(check_mat(Z_dev, ldz, h->Z, "smrt_vae_decode: Z"));
+    if (ldo < h->D) return fail(-1, "smrt_vae_decode: ldo must be >= n_features");
+    HIPC(hipSetDevice(h->device));
+    const long chunk = std::min<long>(n, INFER_CHUNK);
+    TRY(ensure_infer(h, chunk));
+    for (long r0 = 0; r0 < n; r0 += chunk) {
+        const int rows = (int)std::min<long>(chunk, n - r0);
+        TRY(decode_chunk(h, Z_dev + r0 * ldz, ldz, rows, out_dev + r0 * ldo, ldo));
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int smrt_vae_generate(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc, float scale,
+                      float* out_dev, int64_t ldo) {
+    if (!h || !out_dev) return fail(-1, "smrt_vae_generate: null argument");
+    if (n < 0) return fail(-1, "smrt_vae_generate: n must be >= 0");
+    if (n == 0) return 0;
+    if (ldo < h->D) return fail(-1, "smrt_vae_generate: ldo must be >= n_features");
+    HIPC(hipSetDevice(h->device));
+    const long chunk = std::min<long>(n, INFER_CHUNK);
+    TRY(ensure_infer(h, chunk));
+    const long ldz = rup4(h->Z);
+    for (long r0 = 0; r0 < n; r0 += chunk) {
+        const int rows = (int)std::min<long>(chunk, n - r0);
+        launch_sample_normal(h->stream, h->izb, ldz, rows, h->Z, h->cfg.seed, 3u, 0u,
+                             philox_offset + (uint64_t)r0 * h->Z, loc, scale);
+        TRY(decode_chunk(h, h->izb, ldz, rows, out_dev + r0 * ldo, ldo));
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int smrt_vae_sample_eps(smrt_vae* h, int64_t step, int64_t row0, int32_t rows, float* eps_dev) {
+    if (!h || !eps_dev) return fail(-1, "smrt_vae_sample_eps: null argument");
+    HIPC(hipSetDevice(h->device));
+    launch_sample_normal(h->stream, eps_dev, h->Z, rows, h->Z, h->cfg.seed, 1u, (uint32_t)step,
+                         (uint64_t)row0 * h->Z, 0.f, 1.f);
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+// LDS-staged fp32 MFMA tile GEMM for gfx950 (v_mfma_f32_32x32x2_f32, exact fp32 fma chain).
+//
+//   C[M,N] = epilogue( A · B ),   256 threads = 4 waves in a 2x2 arrangement,
+//   block tile (64*WM) x (64*WN), K-tile 32, each wave owns WM x WN sub-tiles of 32x32.
+//
+// Operand layouts (no transposes are ever materialised):
+//   INNER : global [mn][k]  (k contiguous)  -> LDS [mn][36]      read as one ds_read_b128 per 4 k-steps
+//   OUTER : global [k][mn]  (mn contiguous) -> LDS [32][BMN+4]   read as one ds_read_b32 per k-step
+// The k order inside an 8-wide k-block is permuted identically for A and B (lane half h takes
+// k = 8*kb + 4*h + s at step s), which is legal because the MFMA sums over k.
+//
+// MFMA 32x32x2 fragment maps (cdna guide section 3): lane l: r = l & 31, h = l >> 5
+//   A operand: A[m = r][k = h]     B operand: B[k = h][n = r]
+//   C/D reg i: row = (i & 3) + 8 * (i >> 2) + 4 * h, col = r
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace smrt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum Layout : int { INNER = 0, OUTER = 1 };
+
+constexpr int GEMM_THREADS = 256;
+constexpr int BK = 32;
+constexpr int INNER_STRIDE = 36;     // floats; 144 B = 16 B * odd -> conflict-free ds_read_b128
+
+template <int BMN> constexpr int outer_stride() { return BMN + 4; }
+template <int LAY, int BMN> constexpr int lds_floats() {
+    return LAY == INNER ? BMN * INNER_STRIDE : BK * outer_stride<BMN>();
+}
+
+// ------------------------------------------------------------------ global -> register staging
+// ONES: the operand has one virtual extra mn-index (== MN_data) that reads 1.0 for k < K
+// (bias-gradient row of the augmented weight matrix).
+template <int LAY, int BMN, bool ONES>
+struct Stage {
+    static constexpr int PASSES = (LAY == INNER) ? BMN / 32 : (BK * BMN / 4) / GEMM_THREADS;
+    float4 r[PASSES];
+
+    // g: operand base; ld: leading dim (floats, % 4 == 0); mn0: tile origin along mn;
+    // MN_data: number of real mn entries; k0..: tile origin along k; K: k extent.
+    __device__ __forceinline__ void load(const float* __restrict__ g, long ld, int mn0, int MN_data,
+                                         int k0, int K, int tid) {
+        if constexpr (LAY == INNER) {
+            const int row = tid >> 3, kq = (tid & 7) * 4;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int mn = mn0 + row + 32 * p, k = k0 + kq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mn < MN_data && k < K) {
+                    const float* ptr = g + (long)mn * ld + k;
+                    if (k + 3 < K) {
+                        v = *reinterpret_cast<const float4*>(ptr);
+                    } else {
+                        v.x = ptr[0];
+                        if (k + 1 < K) v.y = ptr[1];
+                        if (k + 2 < K) v.z = ptr[2];
+                    }
+                } else if (ONES && mn == MN_data && k < K) {
+                    v.x = 1.f;
+                    if (k + 1 < K) v.y = 1.f;
+                    if (k + 2 < K) v.z = 1.f;
+                    if (k + 3 < K) v.w = 1.f;
+                }
+                r[p] = v;
+            }
+        } else {
+            constexpr int F4 = BMN / 4, RPP = GEMM_THREADS / F4;
+            const int krow = tid / F4, mq = (tid % F4) * 4;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                const int k = k0 + krow + RPP * p, mn = mn0 + mq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K) {
+                    const float* ptr = g + (long)k * ld + mn;
+                    if (mn + 3 < MN_data) {
+                        v = *reinterpret_cast<const float4*>(ptr);
+                    } else {
+                        if (mn < MN_data) v.x = ptr[0];
+                        if (mn + 1 < MN_data) v.y = ptr[1];
+                        if (mn + 2 < MN_data) v.z = ptr[2];
+                        if (ONES) {
+                            if (mn == MN_data) v.x = 1.f;
+                            if (mn + 1 == MN_data) v.y = 1.f;
+                            if (mn + 2 == MN_data) v.z = 1.f;
+                            if (mn + 3 == MN_data) v.w = 1.f;
+                        }
+                    }
+                }
+                r[p] = v;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* lds, int tid) const {
+        if constexpr (LAY == INNER) {
+            const int row = tid >> 3, kq = (tid & 7) * 4;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p)
+                *reinterpret_cast<float4*>(lds + (row + 32 * p) * INNER_STRIDE + kq) = r[p];
+        } else {
+            constexpr int F4 = BMN / 4, RPP = GEMM_THREADS / F4;
+            const int krow = tid / F4, mq = (tid % F4) * 4;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p)
+                *reinterpret_cast<float4*>(lds + (krow + RPP * p) * outer_stride<BMN>() + mq) = r[p];
+        }
+    }
+};
+
+// Fragment for one 8-wide k-block: f[s] feeds MFMA step s.
+template <int LAY, int BMN>
+__device__ __forceinline__ void read_frag(const float* lds, int base_mn, int kb, int r, int h, float (&f)[4]) {
+    if constexpr (LAY == INNER) {
+        const float4 v = *reinterpret_cast<const float4*>(lds + (base_mn + r) * INNER_STRIDE + kb * 8 + 4 * h);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+        const float* p = lds + (kb * 8 + 4 * h) * outer_stride<BMN>() + base_mn + r;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) f[s] = p[s * outer_stride<BMN>()];
+    }
+}
+
+// ------------------------------------------------------------------ block-tile main loop
+// Accumulates A[m0.., kbeg..kend) * B[kbeg..kend), n0..) into acc[WM][WN].
+template <int ALAY, int BLAY, int WM, int WN, bool A_ONES>
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda, int M_data,
+                                          const float* __restrict__ B, long ldb, int N_data,
+                                          int m0, int n0, int kbeg, int kend,
+                                          float* ldsA, float* ldsB, f32x16 (&acc)[WM][WN]) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    Stage<ALAY, BM, A_ONES> sa;
+    Stage<BLAY, BN, false> sb;
+    sa.load(A, lda, m0, M_data, kbeg, kend, tid);
+    sb.load(B, ldb, n0, N_data, kbeg, kend, tid);
+    sa.store(ldsA, tid);
+    sb.store(ldsB, tid);
+    __syncthreads();
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = (k0 + BK) < kend;
+        if (more) {
+            sa.load(A, lda, m0, M_data, k0 + BK, kend, tid);
+            sb.load(B, ldb, n0, N_data, k0 + BK, kend, tid);
+        }
+#pragma unroll
+        for (int kb = 0; kb < BK / 8; ++kb) {
+            float fa[WM][4], fb[WN][4];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) read_frag<ALAY, BM>(ldsA, wr * 32 * WM + i * 32, kb, r, h, fa[i]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) read_frag<BLAY, BN>(ldsB, wc * 32 * WN + j * 32, kb, r, h, fb[j]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            sa.store(ldsA, tid);
+            sb.store(ldsB, tid);
+            __syncthreads();
+        }
+    }
+}
+
+// Visit every accumulator element of this thread: f(row, col, value) with global row/col.
+template <int WM, int WN, class F>
+__device__ __forceinline__ void for_each_c(const f32x16 (&acc)[WM][WN], int m0, int n0, F&& f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wr * 32 * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int col = n0 + wc * 32 * WN + j * 32 + r;
+                f(row, col, acc[i][j][e]);
+            }
+}
+
+}  // namespace smrt

@@ -1,0 +1,387 @@
+// HIP kernels of the VAE train-and-generate hot path (gfx950 / MI355X).
+//
+// Reference call sites replaced (paths relative to the reference root):
+//   dense layer  act(x . dropout(W) + b)                       smrt/autoencode/layer.py:365-368
+//   reparameterisation z = mu + eps * exp(log_sigma)           smrt/autoencode/layer.py:272-279
+//   reconstruction loss (clipped Bernoulli NLL) + its gradient smrt/autoencode/_ae_utils.py:15-32
+//   KL divergence + its gradient                               smrt/autoencode/_ae_utils.py:35-49
+//   L2 penalty, value clip, optimizer.apply_gradients          smrt/autoencode/base.py:127-149
+#include "vae_kernels.hpp"
+#include "device_utils.hpp"
+#include "gemm_mfma_f32.hpp"
+
+namespace smrt {
+
+// =====================================================================================
+// Dense-layer GEMM with fused epilogues
+// =====================================================================================
+template <int ALAY, int BLAY, int WM, int WN, int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    __shared__ __align__(16) float ldsA[lds_floats<ALAY, BM>()];
+    __shared__ __align__(16) float ldsB[lds_floats<BLAY, BN>()];
+    __shared__ float red[4];
+
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    f32x16 acc[WM][WN];
+    gemm_tile<ALAY, BLAY, WM, WN, false>(a.A, a.lda, a.M, a.B, a.ldb, a.N, m0, n0, 0, a.K, ldsA, ldsB, acc);
+
+    if constexpr (EPI == EPI_BIAS_ACT) {
+        // y = act(x.W + b)                                                     layer.py:368
+        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+            if (row < a.M && col < a.N) a.C[(long)row * a.ldc + col] = act_fwd(a.act, v + a.bias[col]);
+        });
+    } else if constexpr (EPI == EPI_HEADS_SPLIT) {
+        // fused (z_mean | z_log_sigma) heads written to two contiguous [n][Z] outputs   autoencoder.py:500
+        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+            if (row < a.M && col < a.N) {
+                const float y = act_fwd(a.act, v + a.bias[col]);
+                if (col < a.Z) a.C[(long)row * a.Z + col] = y;
+                else           a.out2[(long)row * a.Z + (col - a.Z)] = y;
+            }
+        });
+    } else if constexpr (EPI == EPI_BCE) {
+        // last decoder layer: p = sigmoid(.), clipped Bernoulli NLL summed into a block partial, and
+        // dL/dpre emitted directly.                     layer.py:333-338, _ae_utils.py:31-32
+        float lsum = 0.f;
+        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+            if (row < a.M && col < a.N) {
+                const float p = 1.0f / (1.0f + expf(-(v + a.bias[col])));
+                const float x = a.aux[(long)row * a.ldaux + col];
+                const float pl = fmaxf(p, a.lo);
+                const float pc = fminf(pl, a.hi);
+                const float om = 1.0f - pc;
+                lsum -= x * logf(pc) + (1.0f - x) * logf(om);
+                // TF clip_by_value gradient gate: Maximum passes where p >= lo, Minimum where max(p,lo) <= hi
+                const bool pass = (p >= a.lo) && (pl <= a.hi);
+                const float dp = pass ? -(x / pc - (1.0f - x) / om) * a.inv_batch : 0.0f;
+                a.C[(long)row * a.ldc + col] = dp * p * (1.0f - p);
+                if (a.out2) a.out2[(long)row * a.ldout2 + col] = p;
+            }
+        });
+        const float tot = block_sum_256(lsum, red);
+        if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    } else if constexpr (EPI == EPI_ACTGRAD) {
+        // dPre_prev = (dPre . W^T) * act'(y_prev)
+        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+            if (row < a.M && col < a.N)
+                a.C[(long)row * a.ldc + col] = act_bwd(a.act, a.aux[(long)row * a.ldaux + col], v);
+        });
+    } else if constexpr (EPI == EPI_LATENT) {
+        // v = dL/dz.  Through the reparameterisation and the KL term into both heads:
+        //   dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B     layer.py:279, _ae_utils.py:49
+        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+            if (row < a.M && col < a.N) {
+                const float mu = a.aux[(long)row * a.ldaux + col];
+                const float ls = a.aux[(long)row * a.ldaux + a.Z + col];
+                const float e = a.aux2[(long)row * a.ldaux2 + col];
+                const float dmu = v + mu * a.inv_batch;
+                const float dls = v * e * expf(ls) + (expf(2.0f * ls) - 1.0f) * a.inv_batch;
+                a.C[(long)row * a.ldc + col] = act_bwd(a.act, mu, dmu);
+                a.C[(long)row * a.ldc + a.Z + col] = act_bwd(a.act, ls, dls);
+            }
+        });
+    }
+}
+
+static inline bool use_big_tiles(int M, int N) {
+    const long blocks128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    return blocks128 >= 192;
+}
+
+int gemm_grid_blocks(int kind, const GemmArgs& a) {
+    (void)kind;
+    const int t = use_big_tiles(a.M, a.N) ? 128 : 64;
+    return ((a.M + t - 1) / t) * ((a.N + t - 1) / t);
+}
+
+template <int ALAY, int BLAY, int EPI>
+static void launch_gemm_t(hipStream_t s, const GemmArgs& a) {
+    if (use_big_tiles(a.M, a.N)) {
+        dim3 grid((a.N + 127) / 128, (a.M + 127) / 128);
+        hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, 2, 2, EPI>), grid, dim3(GEMM_THREADS), 0, s, a);
+    } else {
+        dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
+        hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, 1, 1, EPI>), grid, dim3(GEMM_THREADS), 0, s, a);
+    }
+}
+
+void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a) {
+    if (kind == GEMM_NN) {
+        if (epi == EPI_BIAS_ACT)         launch_gemm_t<INNER, OUTER, EPI_BIAS_ACT>(s, a);
+        else if (epi == EPI_BCE)         launch_gemm_t<INNER, OUTER, EPI_BCE>(s, a);
+        else                             launch_gemm_t<INNER, OUTER, EPI_HEADS_SPLIT>(s, a);
+    } else {
+        if (epi == EPI_ACTGRAD)          launch_gemm_t<INNER, INNER, EPI_ACTGRAD>(s, a);
+        else                             launch_gemm_t<INNER, INNER, EPI_LATENT>(s, a);
+    }
+}
+
+// =====================================================================================
+// Weight + bias gradients of every layer in one launch:  [X | 1]^T . dPre   (split-K into slabs)
+// =====================================================================================
+template <int WM, int WN>
+__global__ __launch_bounds__(GEMM_THREADS) void dw_kernel(const DwArgs a) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    __shared__ __align__(16) float ldsA[lds_floats<OUTER, BM>()];
+    __shared__ __align__(16) float ldsB[lds_floats<OUTER, BN>()];
+
+    const int t = blockIdx.x;
+    int li = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.n_layers; ++i) if (t >= a.L[i].tile_begin) li = i;
+    const DwLayer& L = a.L[li];
+    const int lt = t - L.tile_begin;
+    const int m0 = (lt / L.tiles_n) * BM, n0 = (lt % L.tiles_n) * BN;
+    const int kbeg = blockIdx.y * a.k_per_split;
+    const int kend = min(a.rows, kbeg + a.k_per_split);
+
+    f32x16 acc[WM][WN];
+    gemm_tile<OUTER, OUTER, WM, WN, true>(L.A, L.lda, L.fi, L.B, L.ldb, L.fo, m0, n0, kbeg, kend, ldsA, ldsB, acc);
+
+    float* C = L.C + (long)blockIdx.y * a.slab_stride;
+    for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+        if (row <= L.fi && col < L.fo) C[(long)row * L.ldc + col] = v;     // row == fi is the bias gradient
+    });
+}
+
+void launch_dw(hipStream_t s, const DwArgs& a, bool big) {
+    dim3 grid(a.total_tiles, a.splits);
+    if (big) hipLaunchKernelGGL((dw_kernel<2, 2>), grid, dim3(GEMM_THREADS), 0, s, a);
+    else     hipLaunchKernelGGL((dw_kernel<1, 1>), grid, dim3(GEMM_THREADS), 0, s, a);
+}
+
+// =====================================================================================
+// Reparameterisation + KL (forward)
+// =====================================================================================
+__global__ __launch_bounds__(256) void reparam_kernel(const float* __restrict__ ML, long ldml,
+                                                      const float* __restrict__ eps_in,
+                                                      float* __restrict__ Zb, float* __restrict__ Eb, long ldz,
+                                                      int rows, int Z, uint64_t seed, const DevState* st,
+                                                      long row0_global, float* kl_partials) {
+    __shared__ float red[4];
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    float kl = 0.f;
+    if (idx < (long)rows * Z) {
+        const int row = (int)(idx / Z), k = (int)(idx % Z);
+        const float mu = ML[(long)row * ldml + k];
+        const float ls = ML[(long)row * ldml + Z + k];
+        const float e = eps_in ? eps_in[idx]
+                               : philox_normal1(seed, STREAM_EPS, st->step, (uint64_t)(row0_global + row) * Z + k);
+        Zb[(long)row * ldz + k] = mu + e * expf(ls);                       // layer.py:279
+        Eb[(long)row * ldz + k] = e;
+        kl = -0.5f * (1.0f + 2.0f * ls - mu * mu - expf(2.0f * ls));       // _ae_utils.py:49
+    }
+    const float tot = block_sum_256(kl, red);
+    if (threadIdx.x == 0) kl_partials[blockIdx.x] = tot;
+}
+
+int reparam_blocks(int rows, int Z) { return (int)(((long)rows * Z + 255) / 256); }
+
+void launch_reparam(hipStream_t s, const float* ML, long ldml, const float* eps_in, float* Zb, float* Eb, long ldz,
+                    int rows, int Z, uint64_t seed, const DevState* st, long row0_global, float* kl_partials) {
+    hipLaunchKernelGGL(reparam_kernel, dim3(reparam_blocks(rows, Z)), dim3(256), 0, s, ML, ldml, eps_in, Zb, Eb, ldz,
+                       rows, Z, seed, st, row0_global, kl_partials);
+}
+
+__global__ __launch_bounds__(256) void sample_normal_kernel(float* out, long ld, long rows, int cols, uint64_t seed,
+                                                            uint32_t stream, uint32_t step, uint64_t elem0,
+                                                            float loc, float scale) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx < rows * cols) {
+        const long row = idx / cols; const int k = (int)(idx % cols);
+        out[row * ld + k] = loc + scale * philox_normal1(seed, stream, step, elem0 + (uint64_t)idx);
+    }
+}
+
+void launch_sample_normal(hipStream_t s, float* out, long ld, long rows, int cols, uint64_t seed, uint32_t stream,
+                          uint32_t step, uint64_t elem0, float loc, float scale) {
+    const long n = rows * cols;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(sample_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, ld, rows, cols,
+                       seed, stream, step, elem0, loc, scale);
+}
+
+// =====================================================================================
+// Dropout on the weights: W' = W / keep * floor(keep + U)                     layer.py:365
+// =====================================================================================
+__device__ __forceinline__ int find_seg(const OptSeg* seg, int n_seg, long i) {
+    int s = 0;
+#pragma unroll 1
+    for (int j = 1; j < n_seg; ++j) if (i >= seg[j].start) s = j;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const DropArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+    const OptSeg& sg = a.seg[find_seg(a.seg, a.n_seg, i)];
+    const long loc = i - sg.start;
+    const int c = (int)(loc % sg.ld);
+    const long rrow = loc / sg.ld;
+    const float w = a.W[i];
+    if (loc >= sg.w_count || c >= sg.fo) {          // bias row / pad column: never dropped
+        a.Wd[i] = w;
+        if (!a.injected) a.mask[i] = 1.0f;
+        return;
+    }
+    float m;
+    if (a.injected) {
+        m = a.mask[i];
+    } else {
+        long e;
+        if (sg.is_heads) e = (c < sg.Z) ? sg.abi_w_off + rrow * sg.Z + c
+                                        : sg.abi_w_off + (long)sg.hfi * sg.Z + rrow * sg.Z + (c - sg.Z);
+        else             e = sg.abi_w_off + rrow * sg.fo + c;
+        m = floorf(a.keep + philox_uniform1(a.seed, STREAM_DROPOUT, a.st->step, (uint64_t)e));
+        a.mask[i] = m;
+    }
+    a.Wd[i] = (w / a.keep) * m;
+}
+
+void launch_dropout(hipStream_t s, const DropArgs& a) {
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((a.P + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// =====================================================================================
+// Fused slab-reduce + L2 + dropout-backward + value clip + optimizer update     base.py:127-149
+// =====================================================================================
+__device__ __forceinline__ float opt_update(const OptArgs& a, float w, float g, float& s0, float& s1, float alpha) {
+    switch (a.opt) {
+        case 1: {   // RMSProp: decay .9, momentum 0, eps 1e-10, rms slot starts at 1
+            s0 = s0 + (g * g - s0) * (1.0f - 0.9f);
+            s1 = s1 * 0.0f + a.lr * g / sqrtf(s0 + 1e-10f);
+            return w - s1;
+        }
+        case 2: {   // Adam: alpha = lr * sqrt(1 - b2^t) / (1 - b1^t), eps 1e-8 outside the sqrt
+            s0 = s0 + (g - s0) * (1.0f - 0.9f);
+            s1 = s1 + (g * g - s1) * (1.0f - 0.999f);
+            return w - alpha * s0 / (sqrtf(s1) + 1e-8f);
+        }
+        case 3: case 6: {   // Adagrad / ProximalAdagrad(l1 = l2 = 0): accumulator starts at 0.1
+            s0 = s0 + g * g;
+            return w - a.lr * g / sqrtf(s0);
+        }
+        case 4: {   // Adadelta: rho .95, eps 1e-8
+            s0 = s0 * 0.95f + g * g * (1.0f - 0.95f);
+            const float upd = sqrtf(s1 + 1e-8f) / sqrtf(s0 + 1e-8f) * g;
+            s1 = s1 * 0.95f + upd * upd * (1.0f - 0.95f);
+            return w - a.lr * upd;
+        }
+        default:    // SGD / ProximalGradientDescent(l1 = l2 = 0)
+            return w - a.lr * g;
+    }
+}
+
+__global__ __launch_bounds__(256) void optimizer_kernel(const OptArgs a) {
+    __shared__ float red[4];
+    const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    float l2acc = 0.f;
+    if (i0 < a.P) {
+        const OptSeg& sg = a.seg[find_seg(a.seg, a.n_seg, i0)];
+        const bool is_w = (i0 - sg.start) < sg.w_count;
+        float4 g = *reinterpret_cast<const float4*>(a.G + i0);
+        for (int s = 1; s < a.splits; ++s) {
+            const float4 t = *reinterpret_cast<const float4*>(a.G + (long)s * a.slab_stride + i0);
+            g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+        }
+        float4 w = *reinterpret_cast<const float4*>(a.W + i0);
+        float gv[4] = {g.x, g.y, g.z, g.w};
+        float wv[4] = {w.x, w.y, w.z, w.w};
+        if (is_w) {
+            float wd[4] = {wv[0], wv[1], wv[2], wv[3]};
+            float mk[4] = {1.f, 1.f, 1.f, 1.f};
+            if (a.has_drop) {
+                const float4 t = *reinterpret_cast<const float4*>(a.Wd + i0);
+                const float4 m = *reinterpret_cast<const float4*>(a.mask + i0);
+                wd[0] = t.x; wd[1] = t.y; wd[2] = t.z; wd[3] = t.w;
+                mk[0] = m.x; mk[1] = m.y; mk[2] = m.z; mk[3] = m.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (a.has_l2 && sg.l2) {
+                    gv[j] += a.l2 * wd[j];                      // tf.nn.l2_loss on the post-dropout tensor
+                    l2acc += 0.5f * wd[j] * wd[j];
+                }
+                if (a.has_drop) gv[j] = (gv[j] / a.keep) * mk[j];   // back through dropout to the variable
+            }
+        }
+        if (a.grad_out) *reinterpret_cast<float4*>(a.grad_out + i0) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        float alpha = 0.f;
+        if (a.opt == 2) alpha = a.lr * sqrtf(1.0f - a.st->b2pow) / (1.0f - a.st->b1pow);
+        float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
+        const bool has_s0 = a.opt != 0 && a.opt != 5;
+        const bool has_s1 = a.opt == 1 || a.opt == 2 || a.opt == 4;
+        if (has_s0) s0 = *reinterpret_cast<const float4*>(a.s0 + i0);
+        if (has_s1) s1 = *reinterpret_cast<const float4*>(a.s1 + i0);
+        float s0v[4] = {s0.x, s0.y, s0.z, s0.w}, s1v[4] = {s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gj = gv[j];
+            if (a.clip) gj = fminf(fmaxf(gj, a.gmin), a.gmax);      // tf.clip_by_value, base.py:144
+            wv[j] = opt_update(a, wv[j], gj, s0v[j], s1v[j], alpha);
+        }
+        *reinterpret_cast<float4*>(a.W + i0) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+        if (has_s0) *reinterpret_cast<float4*>(a.s0 + i0) = make_float4(s0v[0], s0v[1], s0v[2], s0v[3]);
+        if (has_s1) *reinterpret_cast<float4*>(a.s1 + i0) = make_float4(s1v[0], s1v[1], s1v[2], s1v[3]);
+    }
+    const float tot = block_sum_256(l2acc, red);
+    if (threadIdx.x == 0) a.l2_partials[blockIdx.x] = tot;
+}
+
+int optimizer_blocks(long P) { return (int)((P / 4 + 255) / 256); }
+
+void launch_optimizer(hipStream_t s, const OptArgs& a, int* n_blocks_out) {
+    const int nb = optimizer_blocks(a.P);
+    if (n_blocks_out) *n_blocks_out = nb;
+    hipLaunchKernelGGL(optimizer_kernel, dim3(nb), dim3(256), 0, s, a);
+}
+
+// Sum the split-K slabs into one contiguous gradient (data-parallel path hands this to the all-reduce).
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ G, int splits, long slab_stride,
+                                                           long P, float* __restrict__ out) {
+    const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= P) return;
+    float4 g = *reinterpret_cast<const float4*>(G + i0);
+    for (int s = 1; s < splits; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(G + (long)s * slab_stride + i0);
+        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+    }
+    *reinterpret_cast<float4*>(out + i0) = g;
+}
+
+void launch_reduce_slabs(hipStream_t s, const float* G, int splits, long slab_stride, long P, float* out) {
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(optimizer_blocks(P)), dim3(256), 0, s, G, splits, slab_stride, P, out);
+}
+
+// =====================================================================================
+// Cost = mean(rec + kl) + l2 * sum 1/2 |W'|^2 ; advance the step-dependent scalars   autoencoder.py:479-480
+// =====================================================================================
+__global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.n_bce; i += 256) s += a.bce[i];
+    const float bce = block_sum_256(s, red);
+    s = 0.f;
+    for (int i = threadIdx.x; i < a.n_kl; i += 256) s += a.kl[i];
+    const float kl = block_sum_256(s, red);
+    s = 0.f;
+    for (int i = threadIdx.x; i < a.n_l2; i += 256) s += a.l2p[i];
+    const float l2s = block_sum_256(s, red);
+    if (threadIdx.x == 0) {
+        const float data = a.presummed ? a.presummed[0] : (bce + kl) * a.inv_batch;
+        if (a.loss_sum_out) a.loss_sum_out[0] = data;
+        if (a.cost_out) a.cost_out[0] = data + a.l2 * l2s;
+        if (a.advance) {
+            a.st->step += 1;
+            a.st->b1pow *= 0.9f;
+            a.st->b2pow *= 0.999f;
+        }
+    }
+}
+
+void launch_finalize(hipStream_t s, const FinalizeArgs& a) {
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, a);
+}
+
+}  // namespace smrt

@@ -1,0 +1,107 @@
+// Kernel argument blocks and launcher declarations (host <-> vae_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smrt {
+
+constexpr int MAX_LAYERS = 16;      // internal dense layers: 2*L + 2 <= 14
+
+// Device-resident scalars that change every step (read by kernels so a captured graph replays).
+struct DevState {
+    float b1pow, b2pow;      // Adam beta power accumulators (TF keeps them as fp32 variables)
+    uint32_t step;           // number of optimizer steps applied so far
+    uint32_t pad;
+};
+
+enum Epi : int { EPI_BIAS_ACT = 0, EPI_BCE = 1, EPI_HEADS_SPLIT = 2, EPI_ACTGRAD = 3, EPI_LATENT = 4 };
+enum GemmKind : int { GEMM_NN = 0, GEMM_NT = 1 };
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    const float* bias;
+    const float* aux;  long ldaux;      // BCE: target X; ACTGRAD: producing layer's output; LATENT: fused heads output
+    const float* aux2; long ldaux2;     // LATENT: epsilon
+    float* out2;       long ldout2;     // BCE: optional p store; HEADS_SPLIT: log-sigma output
+    float* partials;                    // BCE: one partial loss sum per block
+    int act, Z;
+    float lo, hi, inv_batch;
+};
+
+struct DwLayer {
+    const float* A;      // layer input  [rows][lda]   (K = rows, M = fan_in (+1 virtual ones row -> bias grad))
+    const float* B;      // dPre         [rows][ldb]
+    float* C;            // gradient segment [fan_in + 1][ldc] inside slab 0
+    int fi, fo;
+    long lda, ldb, ldc;
+    int tiles_n, tile_begin;
+};
+struct DwArgs {
+    DwLayer L[MAX_LAYERS];
+    int n_layers, total_tiles;
+    int rows, k_per_split, splits;
+    long slab_stride;
+};
+
+struct OptSeg {
+    long start;          // first float of the segment in the internal flat buffer
+    long w_count;        // fan_in * ld (the bias row follows)
+    long total;          // (fan_in + 1) * ld
+    int ld, fo, l2, is_heads;
+    long abi_w_off;      // first element of this layer's W in the W-only ABI enumeration (dropout stream)
+    int Z, hfi;
+};
+struct OptArgs {
+    OptSeg seg[MAX_LAYERS];
+    int n_seg;
+    long P;
+    float* W; const float* Wd; const float* mask;
+    const float* G; int splits; long slab_stride;
+    float* s0; float* s1;
+    float* grad_out;                 // optional: pre-clip gradient wrt the variables (internal layout)
+    float* l2_partials;
+    const DevState* st;
+    int opt, clip, has_drop, has_l2;
+    float lr, l2, gmin, gmax, keep;
+};
+
+struct DropArgs {
+    OptSeg seg[MAX_LAYERS];
+    int n_seg;
+    long P;
+    const float* W; float* Wd; float* mask;
+    const DevState* st;
+    uint64_t seed;
+    float keep;
+    int injected;                    // masks already in `mask`
+};
+
+struct FinalizeArgs {
+    const float* bce; int n_bce;
+    const float* kl;  int n_kl;
+    const float* l2p; int n_l2;
+    const float* presummed;          // DP: already reduced, already scaled (bce+kl)/B_global
+    float inv_batch, l2;
+    float* cost_out;
+    float* loss_sum_out;             // optional: (bce+kl)*inv_batch without the L2 term
+    DevState* st;
+    int advance;                     // bump step / beta powers
+};
+
+void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a);
+int  gemm_grid_blocks(int kind, const GemmArgs& a);          // number of blocks (= BCE partial count)
+void launch_dw(hipStream_t s, const DwArgs& a, bool big);
+void launch_optimizer(hipStream_t s, const OptArgs& a, int* n_blocks_out);
+int  optimizer_blocks(long P);
+void launch_dropout(hipStream_t s, const DropArgs& a);
+void launch_reparam(hipStream_t s, const float* ML, long ldml, const float* eps_in, float* Zb, float* Eb, long ldz,
+                    int rows, int Z, uint64_t seed, const DevState* st, long row0_global, float* kl_partials);
+int  reparam_blocks(int rows, int Z);
+void launch_finalize(hipStream_t s, const FinalizeArgs& a);
+void launch_reduce_slabs(hipStream_t s, const float* G, int splits, long slab_stride, long P, float* out);
+void launch_sample_normal(hipStream_t s, float* out, long ld, long rows, int cols, uint64_t seed, uint32_t stream,
+                          uint32_t step, uint64_t elem0, float loc, float scale);
+
+}  // namespace smrt

@@ -1,0 +1,300 @@
+"""HIP path vs the CPU oracle, through the C ABI (smrt_amd._hip -> libsmrt_hip.so).
+
+Tolerance: north_star asks for 1e-4 relative in fp32 on per-step loss, gradients and generated
+samples with injected initial weights and epsilon.  Gradients are compared with
+``rtol=1e-4, atol=1e-4 * max|g|`` per tensor (relative to the tensor's scale: single entries can be
+the difference of large cancelling terms).
+"""
+import numpy as np
+import pytest
+
+from oracle.vae_oracle import (ACTIVATIONS, OracleVAE, flatten_params, philox_normal, unflatten_params,
+                               STREAM_EPS, STREAM_GENERATE)
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _handle(D, hidden, Z, act="sigmoid", opt="rms_prop", lr=0.05, l2=1e-4, clip=True, drop=1.0, seed=42,
+            max_batch=256, eps=1e-10, gmin=-5.0, gmax=5.0):
+    from smrt_amd import _hip
+    return _hip.VaeHandle(n_features=D, hidden=hidden, n_latent=Z, activation=act, optimizer=opt, learning_rate=lr,
+                          l2_penalty=l2, clip=clip, gclip_min=gmin, gclip_max=gmax, eps=eps, dropout=drop, seed=seed,
+                          max_batch=max_batch, device=0)
+
+
+def _oracle(D, hidden, Z, act="sigmoid", opt="rms_prop", lr=0.05, l2=1e-4, clip=True, drop=1.0, seed=42,
+            eps=1e-10, gmin=-5.0, gmax=5.0, rs=None, dtype=np.float32):
+    o = OracleVAE(D, hidden, Z, activation=act, learning_function=opt, learning_rate=lr, l2_penalty=l2, clip=clip,
+                  gclip_min=gmin, gclip_max=gmax, eps=eps, dropout=drop, seed=seed, dtype=dtype)
+    if rs is not None:      # decorrelate the identical heads, move biases off zero
+        o.params = [((W + 0.05 * rs.normal(size=W.shape)).astype(dtype), (b + 0.05 * rs.normal(size=b.shape)).astype(dtype))
+                    for W, b in o.params]
+    return o
+
+
+def _close(a, b, what, rtol=RTOL):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * scale, err_msg=what)
+
+
+def _flat_grads(gW, gb):
+    return np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in zip(gW, gb)])
+
+
+def _per_layer(flat, D, hidden, Z):
+    return unflatten_params(flat, D, hidden, Z)
+
+
+@pytest.mark.parametrize("act", ACTIVATIONS)
+@pytest.mark.parametrize("opt", ["rms_prop", "adam", "sgd"])
+def test_three_steps_tiny(act, opt):
+    """Tiny ragged net (D=12, h=7, Z=3, B=5 then B=3): cost, every gradient, weights after 3 steps."""
+    rs = np.random.RandomState(0)
+    D, hidden, Z = 12, [7], 3
+    o = _oracle(D, hidden, Z, act=act, opt=opt, rs=rs)
+    h = _handle(D, hidden, Z, act=act, opt=opt, max_batch=8)
+    h.set_params(flatten_params(o.params))
+    _close(h.get_params(), flatten_params(o.params), "round trip", rtol=0)
+    for step, B in enumerate([5, 3, 5]):
+        X = rs.uniform(0, 1, size=(B, D))
+        eps = rs.normal(size=(B, Z))
+        c_o, (gW, gb) = o.train_step(X, eps, return_grads=True)
+        c_h, g_h = h.train_step(X, eps, want_grads=True)
+        assert np.isclose(c_h, c_o, rtol=RTOL), (step, c_h, c_o)
+        for (hw, hb), w, b in zip(_per_layer(g_h, D, hidden, Z), gW, gb):
+            _close(hw, w, "dW step %d" % step)
+            _close(hb, b, "db step %d" % step)
+    for (hw, hb), (w, b) in zip(_per_layer(h.get_params(), D, hidden, Z), o.params):
+        _close(hw, w, "W after 3 steps")
+        _close(hb, b, "b after 3 steps")
+    assert h.step_count == 3
+    h.close()
+
+
+@pytest.mark.parametrize("opt", ["adagrad", "adadelta", "proximal-sgd", "proximal-adagrad"])
+def test_remaining_optimizers(opt):
+    rs = np.random.RandomState(1)
+    D, hidden, Z = 10, [6, 5], 2
+    o = _oracle(D, hidden, Z, act="tanh", opt=opt, lr=0.1, rs=rs)
+    h = _handle(D, hidden, Z, act="tanh", opt=opt, lr=0.1, max_batch=8)
+    h.set_params(flatten_params(o.params))
+    for _ in range(3):
+        X, eps = rs.uniform(0, 1, size=(6, D)), rs.normal(size=(6, Z))
+        c_o = o.train_step(X, eps)
+        c_h = h.train_step(X, eps)
+        assert np.isclose(c_h, c_o, rtol=RTOL)
+    for (hw, hb), (w, b) in zip(_per_layer(h.get_params(), D, hidden, Z), o.params):
+        _close(hw, w, "W")
+        _close(hb, b, "b")
+    slots = o.opt.state_arrays()
+    first = {"adagrad": "acc", "proximal-adagrad": "acc", "adadelta": "acc"}.get(opt)
+    if first:
+        got = _per_layer(h.get_opt_state(0), D, hidden, Z)
+        for i, (hw, hb) in enumerate(got):
+            _close(hw, slots[first][2 * i], "slot0 W")
+            _close(hb, slots[first][2 * i + 1], "slot0 b")
+    h.close()
+
+
+@pytest.mark.parametrize("clip,l2", [(False, None), (True, None), (False, 1e-2)])
+def test_clip_and_l2_switches(clip, l2):
+    rs = np.random.RandomState(2)
+    D, hidden, Z = 16, [9], 4
+    # tight clip bounds so the clip is active
+    o = _oracle(D, hidden, Z, act="relu", opt="sgd", l2=l2, clip=clip, gmin=-1e-3, gmax=2e-3, rs=rs)
+    h = _handle(D, hidden, Z, act="relu", opt="sgd", l2=l2, clip=clip, gmin=-1e-3, gmax=2e-3, max_batch=16)
+    h.set_params(flatten_params(o.params))
+    X, eps = rs.uniform(0, 1, size=(11, D)), rs.normal(size=(11, Z))
+    c_o, (gW, gb) = o.train_step(X, eps, return_grads=True)
+    c_h, g_h = h.train_step(X, eps, want_grads=True)
+    assert np.isclose(c_h, c_o, rtol=RTOL)
+    _close(g_h, _flat_grads(gW, gb), "pre-clip gradient")
+    _close(h.get_params(), flatten_params(o.params), "params after clipped step")
+    h.close()
+
+
+def test_dropout_injected_masks():
+    rs = np.random.RandomState(3)
+    D, hidden, Z = 12, [8], 3
+    o = _oracle(D, hidden, Z, act="sigmoid", opt="rms_prop", drop=0.5, rs=rs)
+    h = _handle(D, hidden, Z, act="sigmoid", opt="rms_prop", drop=0.5, max_batch=8)
+    h.set_params(flatten_params(o.params))
+    for _ in range(2):
+        masks = [np.floor(0.5 + rs.uniform(size=W.shape)).astype(np.float32) for W, _ in o.params]
+        h.set_dropout_masks(flatten_params([(m, np.ones_like(b)) for m, (_, b) in zip(masks, o.params)]))
+        X, eps = rs.uniform(0, 1, size=(7, D)), rs.normal(size=(7, Z))
+        c_o, (gW, gb) = o.train_step(X, eps, masks=masks, return_grads=True)
+        c_h, g_h = h.train_step(X, eps, want_grads=True)
+        assert np.isclose(c_h, c_o, rtol=RTOL)
+        _close(g_h, _flat_grads(gW, gb), "gradient through dropout")
+    _close(h.get_params(), flatten_params(o.params), "params")
+    h.close()
+
+
+def test_dropout_philox_stream_matches_oracle():
+    rs = np.random.RandomState(4)
+    D, hidden, Z = 12, [8], 3
+    o = _oracle(D, hidden, Z, act="tanh", opt="sgd", drop=0.4, seed=99, rs=rs)
+    h = _handle(D, hidden, Z, act="tanh", opt="sgd", drop=0.4, seed=99, max_batch=8)
+    h.set_params(flatten_params(o.params))
+    for _ in range(2):
+        X, eps = rs.uniform(0, 1, size=(6, D)), rs.normal(size=(6, Z))
+        c_o = o.train_step(X, eps)            # oracle draws its masks from the same Philox stream
+        c_h = h.train_step(X, eps)
+        assert np.isclose(c_h, c_o, rtol=RTOL)
+    _close(h.get_params(), flatten_params(o.params), "params")
+    h.close()
+
+
+def test_philox_epsilon_stream():
+    h = _handle(8, [4], 5, seed=1234567890123, max_batch=8)
+    for step, row0, rows in [(0, 0, 7), (3, 11, 4), (70000, 123456789, 3)]:
+        got = h.sample_eps(step, row0, rows)
+        want = philox_normal(1234567890123, STREAM_EPS, step, row0 * 5, rows * 5).reshape(rows, 5)
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+    big = h.sample_eps(1, 0, 8)
+    h.close()
+    h2 = _handle(8, [4], 5, seed=7, max_batch=8)
+    n = np.concatenate([h2.sample_eps(s, 0, 4000).ravel() for s in range(5)])
+    assert abs(n.mean()) < 0.02 and abs(n.std() - 1) < 0.02
+    h2.close()
+
+
+def test_train_with_kernel_epsilon_matches_oracle():
+    """No injection: the kernels draw epsilon from Philox; the oracle mirrors the stream."""
+    rs = np.random.RandomState(5)
+    D, hidden, Z = 20, [11], 4
+    o = _oracle(D, hidden, Z, act="elu", opt="adam", lr=0.01, seed=2024, rs=rs)
+    h = _handle(D, hidden, Z, act="elu", opt="adam", lr=0.01, seed=2024, max_batch=16)
+    h.set_params(flatten_params(o.params))
+    for B in (16, 9, 16):
+        X = rs.uniform(0, 1, size=(B, D))
+        assert np.isclose(h.train_step(X), o.train_step(X), rtol=RTOL)
+    _close(h.get_params(), flatten_params(o.params), "params", rtol=2e-4)
+    h.close()
+
+
+def test_n1_single_step_and_inference():
+    """MNIST-shaped net (784-450-(10,10)-450-784), B=256 and the ragged B=244 of config 1."""
+    rs = np.random.RandomState(6)
+    D, hidden, Z = 784, [450], 10
+    o = _oracle(D, hidden, Z, rs=rs)
+    h = _handle(D, hidden, Z, max_batch=256)
+    h.set_params(flatten_params(o.params))
+    for B in (256, 244):
+        X = (rs.uniform(0, 1, size=(B, D)) * (rs.uniform(size=(B, D)) > 0.8)).astype(np.float64)
+        eps = rs.normal(size=(B, Z))
+        c_o, (gW, gb) = o.train_step(X, eps, return_grads=True)
+        c_h, g_h = h.train_step(X, eps, want_grads=True)
+        assert np.isclose(c_h, c_o, rtol=RTOL), (c_h, c_o)
+        for (hw, hb), w, b in zip(_per_layer(g_h, D, hidden, Z), gW, gb):
+            _close(hw, w, "dW")
+            _close(hb, b, "db")
+    _close(h.get_params(), flatten_params(o.params), "params")
+    Xe = rs.uniform(0, 1, size=(300, D))
+    mu, ls = h.encode(Xe)
+    mu_o, ls_o = o.encode(Xe)
+    _close(mu, mu_o, "z_mean")
+    _close(ls, ls_o, "z_log_sigma")
+    Zs = rs.normal(size=(333, Z))
+    _close(h.decode(Zs), o.decode(Zs), "decode")
+    h.close()
+
+
+def test_two_hidden_layers_odd_widths():
+    rs = np.random.RandomState(7)
+    D, hidden, Z = 67, [45, 130], 9
+    o = _oracle(D, hidden, Z, act="tanh", opt="rms_prop", rs=rs)
+    h = _handle(D, hidden, Z, act="tanh", opt="rms_prop", max_batch=200)
+    h.set_params(flatten_params(o.params))
+    for B in (200, 131, 1):
+        X, eps = rs.uniform(0, 1, size=(B, D)), rs.normal(size=(B, Z))
+        c_o, (gW, gb) = o.train_step(X, eps, return_grads=True)
+        c_h, g_h = h.train_step(X, eps, want_grads=True)
+        assert np.isclose(c_h, c_o, rtol=RTOL)
+        _close(g_h, _flat_grads(gW, gb), "grads B=%d" % B)
+    _close(h.get_params(), flatten_params(o.params), "params")
+    Zs = rs.normal(size=(5, Z))
+    _close(h.decode(Zs), o.decode(Zs), "decode")
+    assert h.decode(np.zeros((0, Z))).shape == (0, D)              # empty inputs
+    mu0, ls0 = h.encode(np.zeros((0, D)))
+    assert mu0.shape == (0, Z) and ls0.shape == (0, Z)
+    h.close()
+
+
+def test_bce_saturation_matches_ieee():
+    """eps=1e-10: float32(1-eps) == 1.0f, so p == 1.0f is not clipped (inf / NaN cost exactly as IEEE says)."""
+    D, hidden, Z = 4, [3], 2
+    o = _oracle(D, hidden, Z, act="identity", opt="sgd", l2=None)
+    big = [(np.zeros_like(W), np.zeros_like(b)) for W, b in o.params]
+    big[-1] = (big[-1][0], np.array([40.0, -200.0, 40.0, 0.0], np.float32))    # p = 1.0f, ~0, 1.0f, .5
+    o.params = big
+    h = _handle(D, hidden, Z, act="identity", opt="sgd", l2=None, max_batch=4)
+    h.set_params(flatten_params(big))
+    X = np.array([[1.0, 0.0, 0.0, 1.0]])
+    eps = np.zeros((1, Z))
+    with np.errstate(all="ignore"):
+        c_o = o.train_step(X.copy(), eps)
+    c_h = h.train_step(X, eps)
+    assert (np.isnan(c_o) and np.isnan(c_h)) or (np.isinf(c_o) and np.isinf(c_h) and np.sign(c_o) == np.sign(c_h)), (c_o, c_h)
+    h.close()
+    # lower clip: p underflows to < eps -> log(eps), zero gradient through the clip
+    o2 = _oracle(D, hidden, Z, act="identity", opt="sgd", l2=None)
+    p2 = [(np.zeros_like(W), np.zeros_like(b)) for W, b in o2.params]
+    p2[-1] = (p2[-1][0], np.array([-50.0, -50.0, 0.0, 0.0], np.float32))
+    o2.params = p2
+    h2 = _handle(D, hidden, Z, act="identity", opt="sgd", l2=None, max_batch=4)
+    h2.set_params(flatten_params(p2))
+    X2 = np.array([[1.0, 0.0, 0.5, 0.5]])
+    c_o2, (gW, gb) = o2.train_step(X2.copy(), eps, return_grads=True)
+    c_h2, g_h2 = h2.train_step(X2, eps, want_grads=True)
+    assert np.isfinite(c_o2) and np.isclose(c_h2, c_o2, rtol=RTOL)
+    _close(g_h2, _flat_grads(gW, gb), "grads at the lower clip")
+    h2.close()
+
+
+def test_train_epochs_schedule_matches_oracle_fit():
+    """Whole _train loop on device (graph-captured epochs) vs the oracle's per-step loop: contiguous batches,
+    ragged tail, last-batch cost per epoch."""
+    rs = np.random.RandomState(8)
+    D, hidden, Z, n, B = 24, [16], 4, 150, 64          # batches 64, 64, 22
+    o = _oracle(D, hidden, Z, act="sigmoid", opt="rms_prop", seed=11, rs=rs)
+    h = _handle(D, hidden, Z, act="sigmoid", opt="rms_prop", seed=11, max_batch=B)
+    h.set_params(flatten_params(o.params))
+    X = rs.uniform(0, 1, size=(n, D))
+    o.fit(X, n_epochs=4, batch_size=B)
+    costs, ms = h.train_epochs(X, B, 4)
+    assert len(costs) == 4 and np.all(ms > 0)
+    np.testing.assert_allclose(costs, np.array(o.epoch_costs_, np.float32), rtol=2e-4)
+    _close(h.get_params(), flatten_params(o.params), "params after 4 epochs", rtol=5e-4)
+    assert h.step_count == 12
+    h.close()
+
+
+def test_early_stopping_rule():
+    rs = np.random.RandomState(9)
+    D, hidden, Z, n, B = 16, [8], 2, 64, 32
+    o = _oracle(D, hidden, Z, opt="sgd", lr=1e-4, seed=5, rs=rs)
+    h = _handle(D, hidden, Z, opt="sgd", lr=1e-4, seed=5, max_batch=B)
+    h.set_params(flatten_params(o.params))
+    X = rs.uniform(0, 1, size=(n, D))
+    o.fit(X, n_epochs=30, batch_size=B, early_stopping=True, min_change=0.05)
+    costs, _ = h.train_epochs(X, B, 30, early_stopping=True, min_change=0.05)
+    assert len(costs) == len(o.epoch_costs_) < 30
+    np.testing.assert_allclose(costs, np.array(o.epoch_costs_, np.float32), rtol=2e-4)
+    h.close()
+
+
+def test_fast_generate_stream():
+    rs = np.random.RandomState(10)
+    D, hidden, Z = 32, [20], 6
+    o = _oracle(D, hidden, Z, seed=77, rs=rs)
+    h = _handle(D, hidden, Z, seed=77, max_batch=8)
+    h.set_params(flatten_params(o.params))
+    got = h.generate(50, philox_offset=12, loc=0.5, scale=2.0)
+    z = 0.5 + 2.0 * philox_normal(77, STREAM_GENERATE, 0, 12, 50 * Z).reshape(50, Z)
+    _close(got, o.decode(z), "fast generate")
+    h.close()
