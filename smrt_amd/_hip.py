@@ -57,6 +57,10 @@ def load():
         raise HipLibraryError(
             "HIP extension not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C smrt_amd/csrc`. There is no CPU fallback." % _LIB_PATH)
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must be
+    # in the process BEFORE this library is mapped so that both resolve to the same runtime (one HSA
+    # client, shared device pointers); loading /opt/rocm's copy next to it leaves the second one blind.
+    import torch  # noqa: F401
     lib = C.CDLL(_LIB_PATH)
     vp, f32p, i64, i32 = C.c_void_p, C.POINTER(C.c_float), C.c_int64, C.c_int32
     lib.smrt_last_error.restype = C.c_char_p
