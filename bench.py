@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Benchmark of the VAE training hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "C2"): synthetic tabular 1M x 64 binary
+imbalance 1:50 -> the minority class (19 608 rows x 64, fp32 in (0,1)) trains ONE VAE
+64-128-(16,16)-128-64 with the API defaults (batch 128, rms_prop, lr 0.05, l2 1e-4, clip +-5).
+
+A "step" is one training epoch over that class (154 contiguous mini-batches, ragged tail of 24),
+i.e. one pass of the hot path over the batch of synthetic input; value = rows trained per second.
+With --gpus N every rank trains its own minority-class job (the per-class jobs of smrt_balance
+are independent: weak scaling, no collective on the data path).
+
+    python bench.py --gpus 1 --steps 20 --warmup 2
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+D, HIDDEN, Z, BATCH = 64, [128], 16, 128
+N_MINORITY = 19608
+PEAK_MFMA_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md, "HBM3E peak BW"
+
+
+def make_minority(seed):
+    """C2 generator: features sigmoid(N(mu_c, 1)), mu_c ~ N(0,1)^64 per class."""
+    rs = np.random.RandomState(seed)
+    mu = rs.normal(size=D)
+    return (1.0 / (1.0 + np.exp(-(mu + rs.normal(size=(N_MINORITY, D)))))).astype(np.float32)
+
+
+def layer_dims():
+    widths = [D] + HIDDEN
+    enc = list(zip(widths[:-1], widths[1:]))
+    heads = [(widths[-1], 2 * Z)]
+    dec = [(Z, widths[-1])] + [(o, i) for i, o in reversed(enc)]
+    return enc, heads, dec
+
+
+def kind_work(rows_per_epoch, steps_per_epoch):
+    """Algorithmic FLOPs (GEMM kinds) or HBM bytes (optimizer) per epoch, and launches per epoch, per kernel kind."""
+    enc, heads, dec = layer_dims()
+    L = len(enc)
+    R = rows_per_epoch
+    mm = lambda dims: sum(2.0 * R * fi * fo for fi, fo in dims)
+    all_layers = enc + heads + dec
+    p_int = sum((fi + 1) * ((fo + 3) // 4 * 4) for fi, fo in all_layers)
+    return {
+        "fwd_gemm": dict(flops=mm(enc + heads + dec[:-1]), launches=steps_per_epoch * (2 * L + 1)),
+        "fwd_gemm_bce": dict(flops=mm(dec[-1:]), launches=steps_per_epoch),
+        "bwd_gemm": dict(flops=mm(enc[1:] + heads + dec[1:]), launches=steps_per_epoch * (2 * L)),
+        "bwd_gemm_latent": dict(flops=mm(dec[:1]), launches=steps_per_epoch),
+        "fused_fwd_bwd": dict(flops=mm(all_layers) + mm(enc[1:] + heads + dec), launches=steps_per_epoch),
+        "fused_dw_opt": dict(flops=sum(2.0 * R * (fi + 1) * fo for fi, fo in all_layers), launches=steps_per_epoch),
+        "dw_gemm": dict(flops=sum(2.0 * R * (fi + 1) * fo for fi, fo in all_layers), launches=steps_per_epoch),
+        # rms_prop sweep: read G, read+write W, rms, momentum  -> 7 floats per parameter per step
+        "optimizer": dict(bytes=7.0 * 4 * p_int * steps_per_epoch, launches=steps_per_epoch),
+    }
+
+
+def cpu_baseline(X, seconds_budget=12.0):
+    """The CPU restatement of the reference path (oracle, numpy fp32, per-step Python loop like base.py:202-217)
+    timed on a bounded sample of the same workload."""
+    from oracle.vae_oracle import OracleVAE
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = 1
+    o = OracleVAE(D, HIDDEN, Z, seed=42)
+    o.fit(X[:BATCH * 4], n_epochs=1, batch_size=BATCH)          # warm-up
+    epochs, t0 = 0, time.perf_counter()
+    while True:
+        o.fit(X, n_epochs=1, batch_size=BATCH)
+        epochs += 1
+        dt = time.perf_counter() - t0
+        if dt > seconds_budget:
+            break
+    return {"value": epochs * len(X) / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": "%d epoch(s) x %d rows, batch %d (%d steps), numpy fp32 oracle, %.1f s"
+                      % (epochs, len(X), BATCH, epochs * ((len(X) + BATCH - 1) // BATCH), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from smrt_amd import _hip
+    from smrt_amd.autoencode.topography import VAETopography
+
+    X = make_minority(seed=42 + rank)
+    topo = VAETopography(n_hidden=HIDDEN, input_shape=D, activation="sigmoid", n_latent_factors=Z, random_state=42)
+    sess = _hip.VaeHandle(n_features=D, hidden=HIDDEN, n_latent=Z, activation="sigmoid", optimizer="rms_prop",
+                          learning_rate=0.05, l2_penalty=1e-4, clip=True, gclip_min=-5.0, gclip_max=5.0, eps=1e-10,
+                          dropout=1.0, seed=42, max_batch=BATCH, device=local_rank)
+    sess.set_params(VAETopography.join_flat(topo.initial_parameters()))
+    X_dev = _hip.to_device_padded(X, dev)                     # inputs resident in HBM before the timed region
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if args.warmup > 0:
+        sess.train_epochs(X_dev, BATCH, max(args.warmup, 2))  # >= 2 so the epoch graph is built here
+    barrier()
+    t0 = time.perf_counter()
+    costs, epoch_ms = sess.train_epochs(X_dev, BATCH, args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert len(costs) == args.steps and np.all(np.isfinite(costs)), costs
+
+    # ---- per-kernel timing of the same steps, hipEvents on the library's stream (eager launches)
+    steps_per_epoch = (N_MINORITY + BATCH - 1) // BATCH
+    prof_epochs = 2
+    prof = sess.profile_epochs(X_dev, BATCH, prof_epochs)
+    work = kind_work(N_MINORITY, steps_per_epoch)
+    per_kind = {k: {"avg_us": 1e3 * ms / n, "launches_per_epoch": n // prof_epochs, "total_ms_per_epoch": ms / prof_epochs}
+                for k, (ms, n) in prof.items() if n}
+    dom = max((k for k in per_kind if k in work), key=lambda k: per_kind[k]["total_ms_per_epoch"])
+    w, pk = work[dom], per_kind[dom]
+    if "flops" in w:
+        achieved = w["flops"] / w["launches"] / (pk["avg_us"] * 1e-6) / 1e12
+        roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_MFMA_F32_TFLOPS, "traffic": None}
+    else:
+        achieved = w["bytes"] / w["launches"] / (pk["avg_us"] * 1e-6) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+    roof.update({"kernel": dom, "avg_launch_us": pk["avg_us"], "launches_per_step": pk["launches_per_epoch"]})
+
+    if rank == 0:
+        out = {
+            "metric": "VAE train samples/sec", "value": world * N_MINORITY * args.steps / elapsed, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: 1M x 64 binary 1:50 -> minority class 19608 x 64, VAE 64-128-(16,16)-128-64, "
+                                   "one step = one epoch (154 mini-batches of 128, rms_prop)",
+                       "rows_per_step": N_MINORITY, "batch_size": BATCH, "minibatches_per_step": steps_per_epoch,
+                       "parallelism": "1 per-class VAE job per GPU" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "kernels": per_kind,
+            "device_epoch_ms": float(np.mean(epoch_ms)),
+            "kernel_launches_per_step": sess.last_epoch_launches,
+            "final_cost": float(costs[-1]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(X)
+        print(json.dumps(out))
+    sess.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

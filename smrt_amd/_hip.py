@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libsmrt_hip.so")
+_LIB_PATH = os.environ.get("SMRT_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libsmrt_hip.so")
 _lib = None
 
 MAX_HIDDEN = 6
@@ -25,7 +25,7 @@ EXPORTS = [
     "smrt_vae_get_params", "smrt_vae_get_opt_state", "smrt_vae_reset_opt_state", "smrt_vae_step_count",
     "smrt_vae_set_dropout_masks", "smrt_vae_train_step", "smrt_vae_train_epochs", "smrt_vae_dp_count",
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_encode", "smrt_vae_decode",
-    "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches",
+    "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
     "smrt_last_error", "smrt_version",
 ]
 
@@ -85,6 +85,7 @@ def load():
     lib.smrt_vae_decode.argtypes = [vp, vp, i64, i64, vp, i64]
     lib.smrt_vae_generate.argtypes = [vp, i64, C.c_uint64, C.c_float, C.c_float, vp, i64]
     lib.smrt_vae_sample_eps.argtypes = [vp, i64, i64, i32, vp]
+    lib.smrt_vae_profile_epochs.argtypes = [vp, vp, i64, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(i64)]
     _lib = lib
     return lib
 
@@ -234,6 +235,23 @@ class VaeHandle(object):
                                                int(bool(early_stopping)), float(min_change), _f32p(costs), _f32p(ms),
                                                C.byref(done)), "smrt_vae_train_epochs")
         return costs[:done.value].copy(), ms[:done.value].copy()
+
+    PROFILE_KINDS = ("dropout", "fwd_gemm", "fwd_gemm_bce", "reparam", "bwd_gemm", "bwd_gemm_latent", "dw_gemm",
+                     "optimizer", "finalize", "reduce_slabs", "fused_fwd_bwd", "fused_dw_opt")
+
+    def profile_epochs(self, X, batch_size, n_epochs):
+        """Eager epochs with a hipEvent pair around every kernel: {kind: (total ms, launches)}."""
+        Xt, ldx = self._as_dev(X)
+        nk = len(self.PROFILE_KINDS)
+        ms = (C.c_double * nk)()
+        cnt = (C.c_int64 * nk)()
+        _check(self._lib.smrt_vae_profile_epochs(self._live(), Xt.data_ptr(), ldx, Xt.shape[0], int(batch_size),
+                                                 int(n_epochs), ms, cnt), "smrt_vae_profile_epochs")
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}
+
+    @property
+    def last_epoch_launches(self):
+        return int(self._lib.smrt_vae_last_epoch_launches(self._live()))
 
     # -- data-parallel halves
     @property

@@ -58,6 +58,50 @@ struct smrt_vae {
     int last_epoch_launches = 0;
     int use_graph = 1;
     std::vector<hipEvent_t> events;
+
+    // cached epoch graph (valid while X, the schedule and the workspace pointers are unchanged)
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    const float* g_X = nullptr; long g_ldx = 0, g_n = 0, g_batch = 0;
+
+    // row-tile fused forward/backward (small nets): LDS plan
+    bool fused = false;
+    FusedArgs fplan{};
+    unsigned* ticket = nullptr;
+    int tiles16 = 0;
+    int* stage_tab = nullptr;
+
+    // per-kernel profiling (eager launches bracketed by events)
+    bool prof = false;
+    std::vector<hipEvent_t> prof_pool;
+    std::vector<int> prof_kind;
+    size_t prof_used = 0;
+};
+
+enum ProfKind : int { PK_DROPOUT = 0, PK_FWD, PK_FWD_BCE, PK_REPARAM, PK_BWD, PK_BWD_LATENT, PK_DW, PK_OPT,
+                      PK_FINAL, PK_REDUCE, PK_FUSED, PK_FUSED_DW_OPT, PK_COUNT };
+
+static void drop_graph(smrt_vae* h) {
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->gexec = nullptr; h->graph = nullptr; h->g_X = nullptr;
+}
+
+// Bracket one launch with events when profiling; a no-op otherwise.
+struct ProfScope {
+    smrt_vae* h; 
+    ProfScope(smrt_vae* hh, int kind) : h(hh) {
+        if (!h->prof) return;
+        if (h->prof_used + 2 > h->prof_pool.size()) {
+            for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); h->prof_pool.push_back(e); }
+        }
+        h->prof_kind.push_back(kind);
+        (void)hipEventRecord(h->prof_pool[h->prof_used], h->stream);
+    }
+    ~ProfScope() {
+        if (!h->prof) return;
+        (void)hipEventRecord(h->prof_pool[h->prof_used + 1], h->stream);
+        h->prof_used += 2;
+    }
 };
 
 // ------------------------------------------------------------------ layout helpers
@@ -125,6 +169,37 @@ static void fill_segs(const smrt_vae* h, OptSeg* seg) {
     }
 }
 
+static inline int rup16(int v) { return (v + 15) & ~15; }
+
+// LDS plan of the fused row-tile kernel; h->fused says whether the net is small enough to use it.
+static void plan_fused(smrt_vae* h) {
+    FusedArgs& f = h->fplan;
+    f = FusedArgs{};
+    f.NL = h->NL; f.L = h->L; f.Z = h->Z; f.D = h->D;
+    int off = 0, maxw = rup16(h->D);
+    f.s_x = rup16(h->D) + 4; f.lds_x = off; off += 16 * f.s_x;
+    for (int l = 0; l < h->NL; ++l) {
+        const LayerI& y = h->lay[l];
+        FusedLayer& q = f.lay[l];
+        q.fi = y.fi; q.fo = y.fo; q.ld = y.ld; q.act = y.act; q.w_off = (int)y.off;
+        maxw = std::max(maxw, std::max(rup16(y.fo), rup16(y.fi)));
+        if (l < h->NL - 1) { q.s_out = rup16(y.fo) + 4; q.lds_out = off; off += 16 * q.s_out; }
+        q.s_w = rup16(y.fo) + 4; q.lds_w = off; off += rup16(y.fi) * q.s_w;
+        q.lds_b = off; off += rup16(y.fo);
+    }
+    f.s_z = rup16(h->Z) + 4; f.lds_z = off; off += 16 * f.s_z; f.lds_e = off; off += 16 * f.s_z;
+    f.s_d = maxw + 4; f.lds_d0 = off; off += 16 * f.s_d; f.lds_d1 = off; off += 16 * f.s_d;
+    f.lds_total = off;
+    f.w_total = (int)h->P_int;
+    h->tiles16 = 0;
+    for (int l = 0; l < h->NL; ++l) h->tiles16 += ((h->lay[l].fi + 1 + 15) / 16) * ((h->lay[l].fo + 15) / 16);
+    const char* e = std::getenv("SMRT_HIP_FUSED");
+    const bool want = e ? std::atoi(e) != 0 : true;
+    const int bytes = off * (int)sizeof(float);
+    h->fused = want && bytes <= 150 * 1024;
+    if (h->fused && bytes > 48 * 1024 && fused_set_max_lds(bytes) != 0) { (void)hipGetLastError(); h->fused = false; }
+}
+
 template <class T> static int dalloc(T** p, size_t n_elems) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
     if (n_elems == 0) return 0;
@@ -156,10 +231,12 @@ static int choose_splits(const smrt_vae* h, int rows) {
 static int ensure_train(smrt_vae* h, int rows) {
     const int splits = choose_splits(h, rows);
     if (splits > h->g_splits_cap) {
+        drop_graph(h);
         TRY(dalloc(&h->G, (size_t)splits * h->P_int));
         h->g_splits_cap = splits;
     }
     if (rows <= h->cap_rows) return 0;
+    drop_graph(h);
     int cap = std::max(rows, (int)h->cfg.max_batch);
     for (int l = 0; l < h->NL; ++l) {
         if (l < h->NL - 1) TRY(dalloc(&h->out[l], (size_t)cap * h->lay[l].ld));
@@ -167,9 +244,9 @@ static int ensure_train(smrt_vae* h, int rows) {
     }
     TRY(dalloc(&h->Zb, (size_t)cap * rup4(h->Z)));
     TRY(dalloc(&h->Eb, (size_t)cap * rup4(h->Z)));
-    const int nb = ((cap + 63) / 64) * ((h->D + 63) / 64);
+    const int nb = std::max(((cap + 63) / 64) * ((h->D + 63) / 64), (cap + 15) / 16);
     TRY(dalloc(&h->bce_p, (size_t)nb));
-    TRY(dalloc(&h->kl_p, (size_t)reparam_blocks(cap, h->Z)));
+    TRY(dalloc(&h->kl_p, (size_t)std::max(reparam_blocks(cap, h->Z), (cap + 15) / 16)));
     h->cap_rows = cap;
     return 0;
 }
@@ -208,15 +285,45 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         std::memcpy(d.seg, segs, sizeof(OptSeg) * NL); d.n_seg = NL; d.P = h->P_int;
         d.W = h->W; d.Wd = h->Wd; d.mask = h->mask; d.st = h->st; d.seed = h->cfg.seed;
         d.keep = h->cfg.dropout_keep; d.injected = h->masks_injected ? 1 : 0;
-        launch_dropout(s, d); ++launches;
+        { ProfScope ps(h, PK_DROPOUT); launch_dropout(s, d); } ++launches;
         Wuse = h->Wd;
     }
     auto in_of = [&](int l) -> const float* { return l == 0 ? X : (l == L + 1 ? h->Zb : h->out[l - 1]); };
     auto ldin_of = [&](int l) -> long { return l == 0 ? ldx : (l == L + 1 ? (long)rup4(Z) : (long)h->lay[l - 1].ld); };
 
     int n_bce = 0;
+    int n_kl = reparam_blocks(rows, Z);
+    if (h->fused) {
+        FusedArgs f = h->fplan;
+        for (int l = 0; l < NL; ++l) {
+            const LayerI& y = h->lay[l];
+            f.lay[l].W = Wuse + y.off; f.lay[l].bias = h->W + y.off + (long)y.fi * y.ld;
+            f.lay[l].out_g = (l < NL - 1) ? h->out[l] : nullptr; f.lay[l].dpre_g = h->dpre[l];
+        }
+        f.X = X; f.ldx = ldx; f.rows = rows; f.eps_in = eps_in; f.Wflat = Wuse; f.stage_tab = h->stage_tab; f.Zb_g = h->Zb; f.ldz = rup4(Z);
+        f.seed = h->cfg.seed; f.st = h->st; f.row0_global = row0_global;
+        f.lo = h->cfg.bce_lo; f.hi = h->cfg.bce_hi; f.inv_batch = inv_batch; f.bce_p = h->bce_p; f.kl_p = h->kl_p;
+#ifdef SMRT_STAMPS
+        static unsigned long long* dbgbuf = nullptr;
+        if (!dbgbuf) { (void)hipMalloc((void**)&dbgbuf, 64 * 8); (void)hipMemset(dbgbuf, 0, 64 * 8); }
+        f.dbg = dbgbuf;
+#endif
+        { ProfScope ps(h, PK_FUSED); launch_fused_fwd_bwd(s, f); } ++launches;
+#ifdef SMRT_STAMPS
+        {   // diagnostic build: print block 0's phase durations of the 4th launch (wall_clock64 = 100 MHz)
+            (void)hipStreamSynchronize(s);
+            unsigned long long hb[64];
+            (void)hipMemcpy(hb, dbgbuf, 64 * 8, hipMemcpyDeviceToHost);
+            static int once = 0;
+            if (once++ == 3) for (int i = 1; i < 20 && hb[i]; ++i)
+                fprintf(stderr, "stamp %d: +%.2f us  (%.0f shader cycles, %.2f GHz)\n", i, (double)(hb[i] - hb[i - 1]) * 0.01,
+                        (double)(hb[32 + i] - hb[32 + i - 1]), (double)(hb[32 + i] - hb[32 + i - 1]) / ((double)(hb[i] - hb[i - 1]) * 10.0));
+        }
+#endif
+        n_bce = n_kl = (rows + 15) / 16;
+    }
     // ---- forward
-    for (int l = 0; l < NL; ++l) {
+    for (int l = 0; l < NL && !h->fused; ++l) {
         const LayerI& y = h->lay[l];
         GemmArgs a{};
         a.A = in_of(l); a.lda = ldin_of(l);
@@ -224,8 +331,9 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         a.M = rows; a.N = y.fo; a.K = y.fi; a.act = y.act; a.Z = Z;
         if (l < NL - 1) {
             a.C = h->out[l]; a.ldc = y.ld;
-            launch_gemm(s, GEMM_NN, EPI_BIAS_ACT, a); ++launches;
+            { ProfScope ps(h, PK_FWD); launch_gemm(s, GEMM_NN, EPI_BIAS_ACT, a); } ++launches;
             if (l == L) {
+                ProfScope ps(h, PK_REPARAM);
                 launch_reparam(s, h->out[L], y.ld, eps_in, h->Zb, h->Eb, rup4(Z), rows, Z, h->cfg.seed, h->st,
                                row0_global, h->kl_p);
                 ++launches;
@@ -234,11 +342,11 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             a.C = h->dpre[l]; a.ldc = y.ld; a.aux = X; a.ldaux = ldx;
             a.lo = h->cfg.bce_lo; a.hi = h->cfg.bce_hi; a.inv_batch = inv_batch; a.partials = h->bce_p;
             n_bce = gemm_grid_blocks(GEMM_NN, a);
-            launch_gemm(s, GEMM_NN, EPI_BCE, a); ++launches;
+            { ProfScope ps(h, PK_FWD_BCE); launch_gemm(s, GEMM_NN, EPI_BCE, a); } ++launches;
         }
     }
     // ---- backward through the activations
-    for (int l = NL - 1; l >= 1; --l) {
+    for (int l = NL - 1; l >= 1 && !h->fused; --l) {
         const LayerI& y = h->lay[l];
         GemmArgs a{};
         a.A = h->dpre[l]; a.lda = y.ld; a.M = rows; a.K = y.fo;
@@ -247,13 +355,42 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         if (l == L + 1) {
             a.C = h->dpre[L]; a.ldc = h->lay[L].ld; a.aux = h->out[L]; a.ldaux = h->lay[L].ld;
             a.aux2 = h->Eb; a.ldaux2 = rup4(Z); a.act = h->lay[L].act;
-            launch_gemm(s, GEMM_NT, EPI_LATENT, a);
+            { ProfScope ps(h, PK_BWD_LATENT); launch_gemm(s, GEMM_NT, EPI_LATENT, a); }
         } else {
             a.C = h->dpre[l - 1]; a.ldc = h->lay[l - 1].ld; a.aux = h->out[l - 1]; a.ldaux = h->lay[l - 1].ld;
             a.act = h->lay[l - 1].act;
-            launch_gemm(s, GEMM_NT, EPI_ACTGRAD, a);
+            { ProfScope ps(h, PK_BWD); launch_gemm(s, GEMM_NT, EPI_ACTGRAD, a); }
         }
         ++launches;
+    }
+    // ---- small nets, small batches: dW + optimizer in one launch, cost only when somebody reads it
+    if (h->fused && mode == 0 && rows <= 512) {
+        DwOptArgs d{};
+        int tb = 0;
+        for (int l = 0; l < NL; ++l) {
+            const LayerI& y = h->lay[l];
+            DwOptLayer& q = d.L[l];
+            q.A = in_of(l); q.lda = ldin_of(l); q.B = h->dpre[l]; q.ldb = y.ld; q.off = y.off;
+            q.fi = y.fi; q.fo = y.fo; q.ld = y.ld; q.l2 = y.l2;
+            q.tiles_n = (y.fo + 15) / 16; q.tile_begin = tb;
+            tb += ((y.fi + 1 + 15) / 16) * q.tiles_n;
+        }
+        d.n_layers = NL; d.total_tiles = tb; d.rows = rows;
+        d.W = h->W; d.Wd = h->Wd; d.mask = h->mask; d.s0 = h->s0; d.s1 = h->s1; d.grad_out = o.grad_out;
+        d.l2_partials = h->l2_p; d.st = h->st; d.ticket = h->ticket;
+        d.opt = h->cfg.optimizer; d.clip = h->cfg.clip; d.has_drop = h->has_drop; d.has_l2 = h->has_l2;
+        d.lr = h->cfg.learning_rate; d.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
+        d.gmin = h->cfg.gclip_min; d.gmax = h->cfg.gclip_max; d.keep = h->cfg.dropout_keep;
+        { ProfScope ps(h, PK_FUSED_DW_OPT); launch_fused_dw_opt(s, d); } ++launches;
+        if (o.cost_slot) {
+            FinalizeArgs f{};
+            f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p;
+            f.n_l2 = dw_opt_blocks(tb); f.inv_batch = inv_batch; f.l2 = d.l2; f.cost_out = o.cost_slot;
+            f.st = h->st; f.advance = 0;
+            { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
+        }
+        h->last_epoch_launches = launches;
+        return 0;
     }
     // ---- all weight/bias gradients in one launch
     const int splits = std::min(choose_splits(h, rows), h->g_splits_cap);
@@ -273,15 +410,14 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         d.n_layers = NL; d.total_tiles = tb; d.rows = rows; d.splits = splits;
         d.k_per_split = (((rows + splits - 1) / splits) + 31) & ~31;
         d.slab_stride = h->P_int;
-        launch_dw(s, d, big); ++launches;
+        { ProfScope ps(h, PK_DW); launch_dw(s, d, big); } ++launches;
     }
-    const int n_kl = reparam_blocks(rows, Z);
     if (mode == 1) {
-        launch_reduce_slabs(s, h->G, splits, h->P_int, h->P_int, o.dp_out); ++launches;
+        { ProfScope ps(h, PK_REDUCE); launch_reduce_slabs(s, h->G, splits, h->P_int, h->P_int, o.dp_out); } ++launches;
         FinalizeArgs f{};
         f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = nullptr; f.n_l2 = 0;
         f.inv_batch = inv_batch; f.l2 = 0.f; f.loss_sum_out = o.dp_out + h->P_int; f.st = h->st; f.advance = 0;
-        launch_finalize(s, f); ++launches;
+        { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
         h->last_epoch_launches = launches;
         return 0;
     }
@@ -293,11 +429,12 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
     p.opt = h->cfg.optimizer; p.clip = h->cfg.clip; p.has_drop = h->has_drop; p.has_l2 = h->has_l2;
     p.lr = h->cfg.learning_rate; p.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
     p.gmin = h->cfg.gclip_min; p.gmax = h->cfg.gclip_max; p.keep = h->cfg.dropout_keep;
-    launch_optimizer(s, p, nullptr); ++launches;
+    { ProfScope ps(h, PK_OPT); launch_optimizer(s, p, nullptr); } ++launches;
     FinalizeArgs f{};
     f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p; f.n_l2 = h->n_l2;
-    f.inv_batch = inv_batch; f.l2 = p.l2; f.cost_out = o.cost_slot; f.st = h->st; f.advance = 1;
-    launch_finalize(s, f); ++launches;
+    f.inv_batch = inv_batch; f.l2 = p.l2; f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
+    f.st = h->st; f.advance = 1;
+    { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
     h->last_epoch_launches = launches;
     return 0;
 }
@@ -326,6 +463,7 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
     smrt_vae* h = new smrt_vae();
     h->cfg = *cfg; h->device = device;
     build_layers(h);
+    plan_fused(h);
     h->has_drop = cfg->dropout_keep < 1.0f;
     h->has_l2 = cfg->l2_penalty >= 0.f;
     const char* g = std::getenv("SMRT_HIP_GRAPH");
@@ -342,7 +480,22 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
         if ((rc = dalloc(&h->mask, (size_t)h->P_int))) return bail(rc);
     }
     h->n_l2 = optimizer_blocks(h->P_int);
-    if ((rc = dalloc(&h->l2_p, (size_t)h->n_l2))) return bail(rc);
+    if ((rc = dalloc(&h->l2_p, (size_t)std::max(h->n_l2, dw_opt_blocks(h->tiles16))))) return bail(rc);
+    if ((rc = dalloc(&h->ticket, 4))) return bail(rc);
+    if (h->fused) {
+        // where each 16-byte piece of the flat parameter buffer lands in the kernel's LDS weight images
+        std::vector<int> tab((size_t)h->P_int / 4);
+        for (int l = 0; l < h->NL; ++l) {
+            const LayerI& y = h->lay[l];
+            const FusedLayer& q = h->fplan.lay[l];
+            for (int r = 0; r <= y.fi; ++r)
+                for (int c4 = 0; c4 < y.ld; c4 += 4)
+                    tab[(size_t)(y.off + (long)r * y.ld + c4) / 4] = (r < y.fi) ? q.lds_w + r * q.s_w + c4 : q.lds_b + c4;
+        }
+        if ((rc = dalloc(&h->stage_tab, tab.size()))) return bail(rc);
+        if (hipMemcpy(h->stage_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(-2, "stage table upload failed"));
+    }
     if ((rc = dalloc(&h->st, 1))) return bail(rc);
     if ((rc = smrt_vae_reset_opt_state(h))) return bail(rc);
     if ((rc = ensure_train(h, cfg->max_batch))) return bail(rc);
@@ -359,8 +512,12 @@ void smrt_vae_destroy(smrt_vae* h) {
     for (float** b : bufs) if (*b) (void)hipFree(*b);
     for (int l = 0; l < MAX_LAYERS; ++l) { if (h->out[l]) (void)hipFree(h->out[l]); if (h->dpre[l]) (void)hipFree(h->dpre[l]); }
     if (h->st) (void)hipFree(h->st);
+    if (h->ticket) (void)hipFree(h->ticket);
+    if (h->stage_tab) (void)hipFree(h->stage_tab);
     if (h->cost_pin) (void)hipHostFree(h->cost_pin);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
+    drop_graph(h);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -419,6 +576,7 @@ int smrt_vae_reset_opt_state(smrt_vae* h) {
 
 int smrt_vae_set_dropout_masks(smrt_vae* h, const float* host_flat, int64_t n) {
     if (!h) return fail(-1, "smrt_vae_set_dropout_masks: null handle");
+    drop_graph(h);
     if (!host_flat) { h->masks_injected = false; return 0; }
     if (!h->has_drop) return fail(-1, "smrt_vae_set_dropout_masks: handle was created with dropout_keep == 1");
     if (n != h->P_abi) return fail(-1, "smrt_vae_set_dropout_masks: expected " + std::to_string(h->P_abi) + " floats");
@@ -431,8 +589,10 @@ int smrt_vae_set_dropout_masks(smrt_vae* h, const float* host_flat, int64_t n) {
     return 0;
 }
 
+// cost_dev is two floats for the handle's lifetime (slot 0: the cost that is read back, slot 1: scratch for
+// steps whose cost nobody reads) so captured graphs never hold a stale pointer; only the pinned mirror grows.
 static int ensure_cost(smrt_vae* h, long n) {
-    if (n > h->cost_cap) { TRY(dalloc(&h->cost_dev, (size_t)n)); h->cost_cap = n; }
+    if (!h->cost_dev) { TRY(dalloc(&h->cost_dev, 2)); h->cost_cap = 2; }
     if (n > h->cost_pin_cap) {
         if (h->cost_pin) (void)hipHostFree(h->cost_pin);
         h->cost_pin = nullptr;
@@ -489,7 +649,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
         for (long b = 0; b < nb; ++b) {
             const long r0 = b * batch_size;
             const int rows = (int)std::min<long>(batch_size, n_rows - r0);
-            StepOut o{(b == nb - 1) ? slot : h->cost_dev + h->cost_cap - 1, nullptr, nullptr};
+            StepOut o{(b == nb - 1) ? slot : nullptr, nullptr, nullptr};
             TRY(enqueue_step(h, X_dev + r0 * ldx, ldx, rows, 1.0f / (float)rows, 0, nullptr, 0, o));
             launches += h->last_epoch_launches;
         }
@@ -499,22 +659,28 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
 
     // A captured graph replays the identical epoch: every step-dependent scalar (Philox step, Adam powers)
     // lives in device memory, so only the cost slot differs -> the graph writes slot 0 and a copy node moves it.
-    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     bool graphed = false;
-    if (h->use_graph && n_epochs > 1) {
-        if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            int rc = enqueue_epoch(h->cost_dev);
-            hipError_t e = hipStreamEndCapture(h->stream, &graph);
-            if (rc == 0 && e == hipSuccess && graph &&
-                hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess) graphed = true;
-            else { (void)hipGetLastError(); if (graph) (void)hipGraphDestroy(graph); graph = nullptr; if (rc) return rc; }
-        } else (void)hipGetLastError();
+    if (h->use_graph && !h->prof && n_epochs > 1) {
+        const bool hit = h->gexec && h->g_X == X_dev && h->g_ldx == ldx && h->g_n == n_rows && h->g_batch == batch_size;
+        if (hit) graphed = true;
+        else {
+            drop_graph(h);
+            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                int rc = enqueue_epoch(h->cost_dev);
+                hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
+                if (rc == 0 && e == hipSuccess && h->graph &&
+                    hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0) == hipSuccess) {
+                    graphed = true;
+                    h->g_X = X_dev; h->g_ldx = ldx; h->g_n = n_rows; h->g_batch = batch_size;
+                } else { (void)hipGetLastError(); drop_graph(h); if (rc) return rc; }
+            } else (void)hipGetLastError();
+        }
     }
     int done = 0; float last_cost = 0.f; bool have_last = false; int rc = 0;
-    auto cleanup = [&]() { if (gexec) (void)hipGraphExecDestroy(gexec); if (graph) (void)hipGraphDestroy(graph); };
+    auto cleanup = [&]() {};
     auto run_epoch = [&](int ep) -> int {
         HIPC(hipEventRecord(h->events[2 * ep], h->stream));
-        if (graphed) HIPC(hipGraphLaunch(gexec, h->stream));
+        if (graphed) HIPC(hipGraphLaunch(h->gexec, h->stream));
         else TRY(enqueue_epoch(h->cost_dev));
         HIPC(hipEventRecord(h->events[2 * ep + 1], h->stream));
         HIPC(hipMemcpyAsync(h->cost_pin + ep, h->cost_dev, sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -591,6 +757,26 @@ int smrt_vae_apply_grads(smrt_vae* h, const float* grads_dev, float* cost_host) 
     HIPC(hipStreamSynchronize(h->stream));
     h->steps += 1;
     if (cost_host) *cost_host = h->cost_pin[0];
+    return 0;
+}
+
+int smrt_vae_profile_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n_rows, int32_t batch_size,
+                            int32_t n_epochs, double* ms_by_kind, int64_t* launches_by_kind) {
+    if (!h || !ms_by_kind || !launches_by_kind) return fail(-1, "smrt_vae_profile_epochs: null argument");
+    HIPC(hipSetDevice(h->device));
+    h->prof = true; h->prof_used = 0; h->prof_kind.clear();
+    std::vector<float> cost(std::max(n_epochs, 1)), ms(std::max(n_epochs, 1));
+    int32_t done = 0;
+    int rc = smrt_vae_train_epochs(h, X_dev, ldx, n_rows, batch_size, n_epochs, 0, 0.f, cost.data(), ms.data(), &done);
+    h->prof = false;
+    if (rc) return rc;
+    for (int k = 0; k < PK_COUNT; ++k) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; }
+    for (size_t i = 0; i < h->prof_kind.size(); ++i) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, h->prof_pool[2 * i], h->prof_pool[2 * i + 1]);
+        ms_by_kind[h->prof_kind[i]] += t;
+        launches_by_kind[h->prof_kind[i]] += 1;
+    }
     return 0;
 }
 

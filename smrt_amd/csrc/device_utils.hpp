@@ -96,4 +96,18 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Same for a block of NW waves (fixed summation order); `red` = NW floats of LDS.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
+
 }  // namespace smrt

@@ -90,6 +90,58 @@ struct FinalizeArgs {
     int advance;                     // bump step / beta powers
 };
 
+// Row-tile fused forward + backward (fused_small.hip)
+struct FusedLayer {
+    const float* W;       // augmented weights in use (post-dropout when dropout < 1)
+    const float* bias;
+    float* out_g;         // layer output [rows][ld] (null for the last decoder layer)
+    float* dpre_g;        // dL/dpre      [rows][ld]
+    int fi, fo, ld, act;
+    int lds_out, s_out;   // LDS offset / row stride of the layer output tile (floats)
+    int lds_w, s_w;       // LDS offset / row stride of the zero-padded weight image [rup16(fi)][s_w]
+    int lds_b;            // LDS offset of the bias vector [rup16(fo)]
+    int w_off;            // offset of this layer's augmented matrix inside the flat parameter buffer (floats)
+};
+struct FusedArgs {
+    FusedLayer lay[MAX_LAYERS];
+    int NL, L, Z, D;
+    const float* X; long ldx; int rows;
+    const float* Wflat; int w_total;      // flat parameter buffer in use (post-dropout when dropout < 1)
+    const int* stage_tab;                 // [w_total / 4] LDS float offset of every 16-byte piece of Wflat
+    const float* eps_in;
+    float* Zb_g; long ldz;
+    int lds_x, s_x, lds_z, lds_e, s_z, lds_d0, lds_d1, s_d, lds_total;
+    uint64_t seed; const DevState* st; long row0_global;
+    float lo, hi, inv_batch;
+    float* bce_p; float* kl_p;
+    unsigned long long* dbg;      // diagnostic builds only (-DSMRT_STAMPS): phase time stamps of block 0
+};
+void launch_fused_fwd_bwd(hipStream_t s, const FusedArgs& a);
+
+// dW + optimizer fused (fused_small.hip)
+struct DwOptLayer {
+    const float* A;      // layer input [rows][lda]
+    const float* B;      // dPre        [rows][ldb]
+    long lda, ldb, off;  // off: start of the layer's augmented matrix in the flat parameter buffer
+    int fi, fo, ld, l2;
+    int tiles_n, tile_begin;
+};
+struct DwOptArgs {
+    DwOptLayer L[MAX_LAYERS];
+    int n_layers, total_tiles, rows;
+    float* W; const float* Wd; const float* mask;
+    float* s0; float* s1;
+    float* grad_out;
+    float* l2_partials;
+    DevState* st;
+    unsigned* ticket;
+    int opt, clip, has_drop, has_l2;
+    float lr, l2, gmin, gmax, keep;
+};
+void launch_fused_dw_opt(hipStream_t s, const DwOptArgs& a);
+int  dw_opt_blocks(int total_tiles);
+int  fused_set_max_lds(int bytes);
+
 void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a);
 int  gemm_grid_blocks(int kind, const GemmArgs& a);          // number of blocks (= BCE partial count)
 void launch_dw(hipStream_t s, const DwArgs& a, bool big);

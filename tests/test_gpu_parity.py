@@ -16,6 +16,14 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["fused", "per_layer"])
+def kernel_path(request, monkeypatch):
+    """Every case runs twice: with the row-tile fused forward/backward kernel (taken when the net fits in
+    LDS) and with the per-layer GEMM kernels (always taken by large nets)."""
+    monkeypatch.setenv("SMRT_HIP_FUSED", "1" if request.param == "fused" else "0")
+    return request.param
+
+
 def _handle(D, hidden, Z, act="sigmoid", opt="rms_prop", lr=0.05, l2=1e-4, clip=True, drop=1.0, seed=42,
             max_batch=256, eps=1e-10, gmin=-5.0, gmax=5.0):
     from smrt_amd import _hip
