@@ -1,0 +1,200 @@
+"""The drop-in Python surface on the GPU: VariationalAutoEncoder and smrt_balance.
+
+Structural contracts restate the reference's own tests (smrt/autoencode/tests/test_vae.py:19-54,
+smrt/balance/tests/test_smrt.py:12-37) on MNIST-*shaped* synthetic data (real MNIST is a network
+download there); numeric checks compare end-to-end results with the CPU oracle.
+"""
+import numpy as np
+import pytest
+from sklearn.exceptions import NotFittedError
+
+from oracle import balance_oracle
+from oracle.vae_oracle import OracleVAE, init_params
+
+pytestmark = pytest.mark.gpu
+
+
+def mnist_like(n_major, n_minor, d=784, seed=0):
+    """Per-class prototype in [0,1]^d, ~80 % exact zeros (SURVEY 8d stand-in for load_imbalanced_mnist)."""
+    rs = np.random.RandomState(seed)
+    Xs, ys = [], []
+    for label, n in ((1, n_minor), (0, n_major)):          # minority rows first, as the reference loader stacks them
+        proto = rs.uniform(0, 1, size=d) * (rs.uniform(size=d) > 0.8)
+        X = np.clip(proto + 0.15 * rs.normal(size=(n, d)), 0, 1) * (proto > 0)
+        Xs.append(X)
+        ys.append(np.full(n, label))
+    return np.vstack(Xs), np.concatenate(ys)
+
+
+class OracleEstimator(object):
+    """smrt_balance-facing adapter around the oracle VAE (same duck type as the product estimator)."""
+
+    def __init__(self, X_sub, seeded_rs, seed, n_hidden, n_latent, **kw):
+        D = X_sub.shape[1]
+        self.n_latent_factors = n_latent
+        self.rs = seeded_rs
+        fit_kw = {k: kw.pop(k) for k in ("n_epochs", "batch_size")}
+        self.o = OracleVAE(D, n_hidden, n_latent, seed=seed, **kw)
+        self.o.fit(X_sub, **fit_kw)
+
+    def generate(self, n=1, **nrm):
+        return self.o.generate(self.rs, n, **nrm)
+
+    def generate_from_sample(self, X, **nrm):
+        return self.o.generate_from_sample(self.rs, X, **nrm)
+
+
+def test_vae_contract_like_reference_test():
+    from smrt_amd.autoencode import VariationalAutoEncoder
+    X, _ = mnist_like(700, 0, seed=1)
+    X_train, X_test = X[:500], X[500:]
+    ae = VariationalAutoEncoder(n_hidden=400, n_latent_factors=20, n_epochs=10, learning_rate=0.01, batch_size=256,
+                                display_step=5, activation_function='sigmoid', verbose=2, random_state=42,
+                                layer_type='gaussian')
+    with pytest.raises(NotFittedError):
+        ae.generate()
+    ae.fit(X_train)
+    assert ae.topography_.shape == (784, 20, 400, 784)
+    assert len(ae.epoch_costs_) == len(ae.epoch_times_) == 10 and np.isfinite(ae.train_cost_)
+    assert ae.train_cost_ == ae.epoch_costs_[-1]
+    assert ae.epoch_costs_[-1] < ae.epoch_costs_[0]                      # it learns
+    enc = ae.transform(X_train)
+    assert isinstance(enc, list) and len(enc) == 2
+    assert enc[0].shape == enc[1].shape == (500, 20) and enc[0].dtype == np.float32
+    g = ae.generate()
+    assert g.shape == (1, 784) and g.dtype == np.float32 and np.all((g >= 0) & (g <= 1))
+    synth = ae.generate_from_sample(X_test[:5])
+    assert synth.shape[0] == 5
+    w, b = ae.topography_.get_weights_biases()
+    assert [x.shape for x in w] == [(784, 400), (20, 400), (400, 784)] and len(b) == 3
+    ae.fit(X_train[:300])                                                 # refit replaces the session
+    assert ae.transform(X_test)[0].shape == (200, 20)
+    ae.clean_session()
+    with pytest.raises(AttributeError):
+        ae.transform(X_test)
+
+
+def test_vae_error_behaviour_on_fit():
+    from smrt_amd.autoencode import VariationalAutoEncoder
+    X = np.random.RandomState(0).uniform(size=(40, 12))
+    with pytest.raises(UnboundLocalError):                                # base.py:243
+        VariationalAutoEncoder(5, 2, n_epochs=0).fit(X)
+    with pytest.raises(ZeroDivisionError):                                # base.py:225
+        VariationalAutoEncoder(5, 2, n_epochs=2, display_step=0).fit(X)
+    for opt in ("momentum", "adagrad-da"):                                # base.py:138,141
+        with pytest.raises(TypeError):
+            VariationalAutoEncoder(5, 2, learning_function=opt).fit(X)
+    with pytest.raises(ValueError):
+        VariationalAutoEncoder(5, 2, learning_rate=1.0).fit(X)
+    with pytest.raises(ValueError):
+        VariationalAutoEncoder(5, 2).fit(np.array([[np.nan] * 4] * 4))
+    hidden = [7, 5]
+    v = VariationalAutoEncoder(hidden, 0.25, n_epochs=1).fit(X)
+    assert hidden == [7, 5] and v.topography_.n_latent_factors == 3 and v.topography_.shape == (12, 7, 3, 5, 7, 12)
+    with pytest.raises(TypeError):                                        # float latent breaks generate (autoencoder.py:571)
+        v.generate(2)
+    with pytest.raises(ValueError):
+        v.feed_forward(np.zeros((2, 9)))
+
+
+@pytest.mark.parametrize("opt,act", [("rms_prop", "sigmoid"), ("adam", "tanh"), ("sgd", "relu")])
+def test_fit_generate_match_oracle(opt, act):
+    from smrt_amd.autoencode import VariationalAutoEncoder
+    rs = np.random.RandomState(3)
+    X = rs.uniform(0, 1, size=(300, 30))
+    kw = dict(learning_rate=0.01, l2_penalty=1e-4)
+    ae = VariationalAutoEncoder(n_hidden=[24, 12], n_latent_factors=5, n_epochs=3, batch_size=128, random_state=9,
+                                learning_function=opt, activation_function=act, **kw).fit(X)
+    o = OracleVAE(30, [24, 12], 5, activation=act, learning_function=opt, seed=9, **kw)
+    o.fit(X, n_epochs=3, batch_size=128)
+    np.testing.assert_allclose(ae.epoch_costs_, np.array(o.epoch_costs_), rtol=3e-4)
+    for (W, b), (Wo, bo) in zip(ae.get_weights(), o.params):
+        np.testing.assert_allclose(W, Wo, rtol=1e-3, atol=2e-5)
+        np.testing.assert_allclose(b, bo, rtol=1e-3, atol=2e-5)
+    o_rs = np.random.RandomState(9)                                       # generate() consumes random_state_
+    np.testing.assert_allclose(ae.generate(7), o.generate(o_rs, 7), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ae.generate(3, loc=0.5, scale=2.0), o.generate(o_rs, 3, loc=0.5, scale=2.0),
+                               rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ae.generate_from_sample(X[:11]), o.generate_from_sample(o_rs, X[:11]),
+                               rtol=1e-3, atol=1e-5)
+    mu, ls = ae.transform(X[:50])
+    mu_o, ls_o = o.encode(X[:50])
+    np.testing.assert_allclose(mu, mu_o, rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ls, ls_o, rtol=1e-3, atol=1e-5)
+
+
+def test_weight_injection_and_checkpoint_roundtrip():
+    from smrt_amd.autoencode import VariationalAutoEncoder
+    rs = np.random.RandomState(4)
+    X = rs.uniform(0, 1, size=(64, 10))
+    params = init_params(10, [6], 3, layer_type="gaussian", seed=123)
+    params = [(W + 0.1 * rs.normal(size=W.shape).astype(np.float32), b + 0.1) for W, b in params]
+    ae = VariationalAutoEncoder(6, 3, n_epochs=2, batch_size=32, random_state=1, learning_function="sgd",
+                                learning_rate=0.01).set_initial_weights(params).fit(X)
+    o = OracleVAE(10, [6], 3, learning_function="sgd", learning_rate=0.01, seed=1, params=params)
+    o.fit(X, n_epochs=2, batch_size=32)
+    np.testing.assert_allclose(ae.epoch_costs_, np.array(o.epoch_costs_), rtol=2e-4)
+    saved = ae.get_weights()
+    z = rs.normal(size=(4, 3))
+    before = ae.feed_forward(z)
+    ae.set_weights([(W * 0, b * 0) for W, b in saved])
+    assert np.allclose(ae.feed_forward(z), 0.5)
+    ae.set_weights(saved)
+    np.testing.assert_array_equal(ae.feed_forward(z), before)
+
+
+def test_smrt_balance_counts_like_reference_test():
+    """test_smrt.py:12-37 on the MNIST-shaped stand-in: 5444 zeros + 500 ones -> 8166 rows, 2722 ones."""
+    from smrt_amd.balance import smrt_balance
+    X, y = mnist_like(5444, 500, seed=2)
+    assert X.shape[0] == y.shape[0] == 5944
+
+    def _fit(prefit_estimators=None, return_estimators=False, gen_from_samples=False):
+        return smrt_balance(X, y, n_hidden=450, n_latent_factors=10, learning_rate=0.05,
+                            activation_function='sigmoid', verbose=0, display_step=25, n_epochs=50, batch_size=256,
+                            random_state=42, shuffle=False, balance_ratio=0.5, return_estimators=return_estimators,
+                            prefit_estimators=prefit_estimators, gen_from_samples=gen_from_samples)
+
+    def _assert(x, yy):
+        assert x.shape[0] == yy.shape[0] == 8166 and x.dtype == np.float64
+        assert yy[yy == 1].shape[0] == x[yy == 1].shape[0] == 2722
+        assert yy[yy == 0].shape[0] == x[yy == 0].shape[0] == 5444
+        assert np.all(np.isfinite(x)) and x.min() >= 0 and x.max() <= 1
+        np.testing.assert_array_equal(x[:5944], X)                       # originals first when shuffle=False
+
+    X_smrt, y_smrt, encoders = _fit(return_estimators=True)
+    _assert(X_smrt, y_smrt)
+    assert encoders[0] is None and encoders[1] is not None
+    _assert(*_fit(prefit_estimators=encoders))
+    _assert(*_fit(gen_from_samples=True))
+
+
+@pytest.mark.parametrize("gen_from_samples", [False, True])
+def test_smrt_balance_matches_oracle_end_to_end(gen_from_samples):
+    """Three minority classes, shuffled output: every synthetic row equals the oracle's (same numpy stream
+    order, same Philox epsilon stream, same initial weights)."""
+    from smrt_amd.balance import smrt_balance
+    rs = np.random.RandomState(5)
+    D = 20
+    counts = {0: 120, 1: 30, 2: 12, 3: 50}
+    Xs, ys = [], []
+    for lab, n in counts.items():
+        c = rs.uniform(0.2, 0.8, size=D)
+        Xs.append(np.clip(c + 0.1 * rs.normal(size=(n, D)), 0, 1))
+        ys.append(np.full(n, lab))
+    perm = rs.permutation(sum(counts.values()))
+    X, y = np.vstack(Xs)[perm], np.concatenate(ys)[perm]
+    kw = dict(learning_rate=0.01, l2_penalty=1e-4)
+    Xb, yb, enc = smrt_balance(X, y, n_hidden=16, n_latent_factors=4, balance_ratio=0.5, n_epochs=3, batch_size=16,
+                               random_state=11, shuffle=True, gen_from_samples=gen_from_samples,
+                               return_estimators=True, generate_args={"scale": 0.5}, **kw)
+
+    def make(X_sub, rstate):
+        return OracleEstimator(X_sub, rstate, 11, [16], 4, n_epochs=3, batch_size=16, **kw)
+
+    Xo, yo = balance_oracle.balance(X, y, make, balance_ratio=0.5, random_state=11, shuffle=True,
+                                    gen_from_samples=gen_from_samples, generate_args={"scale": 0.5})
+    np.testing.assert_array_equal(yb, yo)
+    assert Xb.shape == Xo.shape == (120 + 60 + 60 + 60, D)
+    np.testing.assert_allclose(Xb, Xo, rtol=1e-3, atol=1e-5)
+    assert enc[0] is None and all(enc[k] is not None for k in (1, 2, 3))
