@@ -45,6 +45,10 @@ struct smrt_vae {
     float* out[MAX_LAYERS] = {nullptr};
     float* dpre[MAX_LAYERS] = {nullptr};
     float *Zb = nullptr, *Eb = nullptr;
+    // transposed workspace of the fused small-net path ([feature][capT], rows contiguous)
+    float* outT[MAX_LAYERS] = {nullptr};
+    float* dpreT[MAX_LAYERS] = {nullptr};
+    float *XT = nullptr, *ZT = nullptr;
     float *bce_p = nullptr, *kl_p = nullptr, *l2_p = nullptr;
     int n_l2 = 0;
     float* cost_dev = nullptr; long cost_cap = 0;
@@ -184,8 +188,8 @@ static void plan_fused(smrt_vae* h) {
         q.fi = y.fi; q.fo = y.fo; q.ld = y.ld; q.act = y.act; q.w_off = (int)y.off;
         maxw = std::max(maxw, std::max(rup16(y.fo), rup16(y.fi)));
         if (l < h->NL - 1) { q.s_out = rup16(y.fo) + 4; q.lds_out = off; off += 16 * q.s_out; }
-        q.s_w = rup16(y.fo) + 4; q.lds_w = off; off += rup16(y.fi) * q.s_w;
-        q.lds_b = off; off += rup16(y.fo);
+        q.nn = rup16(y.fo) + 1; q.lds_w = off; off += (rup16(y.fi) / 4) * q.nn * 4;
+        q.lds_b = off; off += 4 * rup16(y.fo);
     }
     f.s_z = rup16(h->Z) + 4; f.lds_z = off; off += 16 * f.s_z; f.lds_e = off; off += 16 * f.s_z;
     f.s_d = maxw + 4; f.lds_d0 = off; off += 16 * f.s_d; f.lds_d1 = off; off += 16 * f.s_d;
@@ -237,10 +241,18 @@ static int ensure_train(smrt_vae* h, int rows) {
     }
     if (rows <= h->cap_rows) return 0;
     drop_graph(h);
-    int cap = std::max(rows, (int)h->cfg.max_batch);
+    int cap = (std::max(rows, (int)h->cfg.max_batch) + 15) & ~15;     // fused kernels store whole 16-row tiles
     for (int l = 0; l < h->NL; ++l) {
         if (l < h->NL - 1) TRY(dalloc(&h->out[l], (size_t)cap * h->lay[l].ld));
         TRY(dalloc(&h->dpre[l], (size_t)cap * h->lay[l].ld));
+    }
+    if (h->fused) {
+        for (int l = 0; l < h->NL; ++l) {
+            if (l < h->NL - 1) TRY(dalloc(&h->outT[l], (size_t)cap * rup16(h->lay[l].fo)));
+            TRY(dalloc(&h->dpreT[l], (size_t)cap * rup16(h->lay[l].fo)));
+        }
+        TRY(dalloc(&h->XT, (size_t)cap * rup16(h->D)));
+        TRY(dalloc(&h->ZT, (size_t)cap * rup16(h->Z)));
     }
     TRY(dalloc(&h->Zb, (size_t)cap * rup4(h->Z)));
     TRY(dalloc(&h->Eb, (size_t)cap * rup4(h->Z)));
@@ -293,14 +305,16 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
 
     int n_bce = 0;
     int n_kl = reparam_blocks(rows, Z);
-    if (h->fused) {
+    const bool fused_step = h->fused && mode == 0 && rows <= 512;      // two-kernel step on the transposed workspace
+    if (fused_step) {
         FusedArgs f = h->fplan;
         for (int l = 0; l < NL; ++l) {
             const LayerI& y = h->lay[l];
             f.lay[l].W = Wuse + y.off; f.lay[l].bias = h->W + y.off + (long)y.fi * y.ld;
-            f.lay[l].out_g = (l < NL - 1) ? h->out[l] : nullptr; f.lay[l].dpre_g = h->dpre[l];
+            f.lay[l].out_g = (l < NL - 1) ? h->outT[l] : nullptr; f.lay[l].dpre_g = h->dpreT[l];
         }
-        f.X = X; f.ldx = ldx; f.rows = rows; f.eps_in = eps_in; f.Wflat = Wuse; f.stage_tab = h->stage_tab; f.Zb_g = h->Zb; f.ldz = rup4(Z);
+        f.X = X; f.ldx = ldx; f.rows = rows; f.eps_in = eps_in; f.Wflat = Wuse; f.stage_tab = h->stage_tab; f.Zb_g = h->ZT;
+        f.XT = h->XT; f.ldT = h->cap_rows;
         f.seed = h->cfg.seed; f.st = h->st; f.row0_global = row0_global;
         f.lo = h->cfg.bce_lo; f.hi = h->cfg.bce_hi; f.inv_batch = inv_batch; f.bce_p = h->bce_p; f.kl_p = h->kl_p;
 #ifdef SMRT_STAMPS
@@ -323,7 +337,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         n_bce = n_kl = (rows + 15) / 16;
     }
     // ---- forward
-    for (int l = 0; l < NL && !h->fused; ++l) {
+    for (int l = 0; l < NL && !fused_step; ++l) {
         const LayerI& y = h->lay[l];
         GemmArgs a{};
         a.A = in_of(l); a.lda = ldin_of(l);
@@ -346,7 +360,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         }
     }
     // ---- backward through the activations
-    for (int l = NL - 1; l >= 1 && !h->fused; --l) {
+    for (int l = NL - 1; l >= 1 && !fused_step; --l) {
         const LayerI& y = h->lay[l];
         GemmArgs a{};
         a.A = h->dpre[l]; a.lda = y.ld; a.M = rows; a.K = y.fo;
@@ -364,24 +378,38 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         ++launches;
     }
     // ---- small nets, small batches: dW + optimizer in one launch, cost only when somebody reads it
-    if (h->fused && mode == 0 && rows <= 512) {
+    if (fused_step) {
         DwOptArgs d{};
         int tb = 0;
         for (int l = 0; l < NL; ++l) {
             const LayerI& y = h->lay[l];
             DwOptLayer& q = d.L[l];
-            q.A = in_of(l); q.lda = ldin_of(l); q.B = h->dpre[l]; q.ldb = y.ld; q.off = y.off;
+            q.A = (l == 0) ? h->XT : (l == L + 1 ? h->ZT : h->outT[l - 1]); q.B = h->dpreT[l]; q.off = y.off;
             q.fi = y.fi; q.fo = y.fo; q.ld = y.ld; q.l2 = y.l2;
             q.tiles_n = (y.fo + 15) / 16; q.tile_begin = tb;
             tb += ((y.fi + 1 + 15) / 16) * q.tiles_n;
         }
-        d.n_layers = NL; d.total_tiles = tb; d.rows = rows;
+        d.n_layers = NL; d.total_tiles = tb; d.rows = rows; d.ldT = h->cap_rows;
         d.W = h->W; d.Wd = h->Wd; d.mask = h->mask; d.s0 = h->s0; d.s1 = h->s1; d.grad_out = o.grad_out;
         d.l2_partials = h->l2_p; d.st = h->st; d.ticket = h->ticket;
         d.opt = h->cfg.optimizer; d.clip = h->cfg.clip; d.has_drop = h->has_drop; d.has_l2 = h->has_l2;
         d.lr = h->cfg.learning_rate; d.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
         d.gmin = h->cfg.gclip_min; d.gmax = h->cfg.gclip_max; d.keep = h->cfg.dropout_keep;
+#ifdef SMRT_STAMPS
+        static unsigned long long* dbgb = nullptr;
+        if (!dbgb) { (void)hipMalloc((void**)&dbgb, 64 * 8); (void)hipMemset(dbgb, 0, 64 * 8); }
+        d.dbg = dbgb;
+#endif
         { ProfScope ps(h, PK_FUSED_DW_OPT); launch_fused_dw_opt(s, d); } ++launches;
+#ifdef SMRT_STAMPS
+        {
+            (void)hipStreamSynchronize(s);
+            unsigned long long hb[64];
+            (void)hipMemcpy(hb, dbgb, 64 * 8, hipMemcpyDeviceToHost);
+            static int onceb = 0;
+            if (onceb++ == 3) for (int i = 21; i < 25; ++i) fprintf(stderr, "dw_opt stamp %d: +%.2f us\n", i, (double)(hb[i] - hb[i - 1]) * 0.01);
+        }
+#endif
         if (o.cost_slot) {
             FinalizeArgs f{};
             f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p;
@@ -490,7 +518,8 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
             const FusedLayer& q = h->fplan.lay[l];
             for (int r = 0; r <= y.fi; ++r)
                 for (int c4 = 0; c4 < y.ld; c4 += 4)
-                    tab[(size_t)(y.off + (long)r * y.ld + c4) / 4] = (r < y.fi) ? q.lds_w + r * q.s_w + c4 : q.lds_b + c4;
+                    tab[(size_t)(y.off + (long)r * y.ld + c4) / 4] =
+                        (r < y.fi) ? q.lds_w + (((r >> 2) * q.nn + c4) << 2) + (r & 3) : q.lds_b + 4 * c4;
         }
         if ((rc = dalloc(&h->stage_tab, tab.size()))) return bail(rc);
         if (hipMemcpy(h->stage_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
@@ -510,7 +539,12 @@ void smrt_vae_destroy(smrt_vae* h) {
     float** bufs[] = {&h->W, &h->Wd, &h->mask, &h->s0, &h->s1, &h->G, &h->gtmp, &h->Zb, &h->Eb, &h->bce_p, &h->kl_p,
                       &h->l2_p, &h->cost_dev, &h->ibuf[0], &h->ibuf[1], &h->izb};
     for (float** b : bufs) if (*b) (void)hipFree(*b);
-    for (int l = 0; l < MAX_LAYERS; ++l) { if (h->out[l]) (void)hipFree(h->out[l]); if (h->dpre[l]) (void)hipFree(h->dpre[l]); }
+    for (int l = 0; l < MAX_LAYERS; ++l) {
+        float* b4[] = {h->out[l], h->dpre[l], h->outT[l], h->dpreT[l]};
+        for (float* b : b4) if (b) (void)hipFree(b);
+    }
+    if (h->XT) (void)hipFree(h->XT);
+    if (h->ZT) (void)hipFree(h->ZT);
     if (h->st) (void)hipFree(h->st);
     if (h->ticket) (void)hipFree(h->ticket);
     if (h->stage_tab) (void)hipFree(h->stage_tab);

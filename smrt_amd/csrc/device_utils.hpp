@@ -30,6 +30,51 @@ __device__ __forceinline__ float act_bwd(int act, float y, float dy) {
     }
 }
 
+// Four values at once with ONE (uniform) switch: lets the compiler interleave the four dependency chains.
+__device__ __forceinline__ void act_fwd4(int act, float (&v)[4]) {
+    switch (act) {
+        case ACT_SIGMOID:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+            break;
+        case ACT_TANH:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            break;
+        case ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+            break;
+        case ACT_ELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : expm1f(v[r]);
+            break;
+        default: break;
+    }
+}
+
+__device__ __forceinline__ void act_bwd4(int act, const float (&y)[4], float (&dy)[4]) {
+    switch (act) {
+        case ACT_SIGMOID:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dy[r] = dy[r] * y[r] * (1.0f - y[r]);
+            break;
+        case ACT_TANH:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dy[r] = dy[r] * (1.0f - y[r] * y[r]);
+            break;
+        case ACT_RELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dy[r] = y[r] > 0.0f ? dy[r] : 0.0f;
+            break;
+        case ACT_ELU:
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dy[r] = y[r] < 0.0f ? dy[r] * (y[r] + 1.0f) : dy[r];
+            break;
+        default: break;
+    }
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 // Counter-based RNG (Salmon et al., SC'11).  Streams: 1 = training epsilon, 2 = dropout, 3 = generate.
 // Mirrored bit-for-bit by oracle/vae_oracle.py: philox4x32_10.

@@ -43,23 +43,27 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+// Weight image in LDS ("k-quad interleaved"): element W[kf][nf] (kf = fan-in index, nf = fan-out index) lives at
+//   ((kf >> 2) * nn + nf) * 4 + (kf & 3)      floats, nn = rup16(fan_out) + 1 (odd -> conflict-free strided reads)
+// Forward  (sum over kf): a lane's four k values are contiguous       -> ONE ds_read_b128.
+// Backward (sum over nf): a lane's four k values are 16 bytes apart   -> ds_read with immediate offsets.
 template <bool TRANS>
-__device__ __forceinline__ void load_frags(const float* A_lds, int sa, const float* W_lds, int sw, int c, int q, int n,
+__device__ __forceinline__ void load_frags(const float* A_lds, int sa, const float* W_lds, int nn, int c, int q, int n,
                                            int k0, float4& a, float4& b) {
     const int k = k0 + 4 * q;
     a = *reinterpret_cast<const float4*>(A_lds + c * sa + k);
     if constexpr (TRANS) {
-        b = *reinterpret_cast<const float4*>(W_lds + n * sw + k);          // Wop[k][n] = W[n][k]
+        const float* p = W_lds + (((n >> 2) * nn + k) << 2) + (n & 3);    // Wop[k][n] = W[kf = n][nf = k]
+        b = make_float4(p[0], p[4], p[8], p[12]);
     } else {
-        const float* p = W_lds + k * sw + n;                              // Wop[k][n] = W[k][n]
-        b = make_float4(p[0], p[sw], p[2 * sw], p[3 * sw]);
+        b = *reinterpret_cast<const float4*>(W_lds + ((((k0 >> 2) + q) * nn + n) << 2));   // Wop[k][n] = W[kf = k][nf = n]
     }
 }
 
 // C[16 x N] = A_lds[16 x K16] . Wop, all operands in LDS, zero padded to multiples of 16.
-// epi(row, col, value) is called for col < N only.
+// epi(row0, col, v[4]) is called once per lane for col < N with the values of rows row0 .. row0+3.
 template <bool TRANS, class Epi>
-__device__ __forceinline__ void tile_gemm16(const float* A_lds, int sa, int K16, const float* W_lds, int sw,
+__device__ __forceinline__ void tile_gemm16(const float* A_lds, int sa, int K16, const float* W_lds, int nn,
                                             int N, Epi&& epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
@@ -69,10 +73,10 @@ __device__ __forceinline__ void tile_gemm16(const float* A_lds, int sa, int K16,
         int k0 = 0;
         for (; k0 + 64 <= K16; k0 += 64) {
             float4 a0, a1, a2, a3, b0, b1, b2, b3;
-            load_frags<TRANS>(A_lds, sa, W_lds, sw, c, q, n, k0, a0, b0);
-            load_frags<TRANS>(A_lds, sa, W_lds, sw, c, q, n, k0 + 16, a1, b1);
-            load_frags<TRANS>(A_lds, sa, W_lds, sw, c, q, n, k0 + 32, a2, b2);
-            load_frags<TRANS>(A_lds, sa, W_lds, sw, c, q, n, k0 + 48, a3, b3);
+            load_frags<TRANS>(A_lds, sa, W_lds, nn, c, q, n, k0, a0, b0);
+            load_frags<TRANS>(A_lds, sa, W_lds, nn, c, q, n, k0 + 16, a1, b1);
+            load_frags<TRANS>(A_lds, sa, W_lds, nn, c, q, n, k0 + 32, a2, b2);
+            load_frags<TRANS>(A_lds, sa, W_lds, nn, c, q, n, k0 + 48, a3, b3);
             MFMA16(a0.x, b0.x, acc0); MFMA16(a1.x, b1.x, acc1); MFMA16(a2.x, b2.x, acc2); MFMA16(a3.x, b3.x, acc3);
             MFMA16(a0.y, b0.y, acc0); MFMA16(a1.y, b1.y, acc1); MFMA16(a2.y, b2.y, acc2); MFMA16(a3.y, b3.y, acc3);
             MFMA16(a0.z, b0.z, acc0); MFMA16(a1.z, b1.z, acc1); MFMA16(a2.z, b2.z, acc2); MFMA16(a3.z, b3.z, acc3);
@@ -80,12 +84,14 @@ __device__ __forceinline__ void tile_gemm16(const float* A_lds, int sa, int K16,
         }
         for (; k0 < K16; k0 += 16) {
             float4 a0, b0;
-            load_frags<TRANS>(A_lds, sa, W_lds, sw, c, q, n, k0, a0, b0);
+            load_frags<TRANS>(A_lds, sa, W_lds, nn, c, q, n, k0, a0, b0);
             MFMA16(a0.x, b0.x, acc0); MFMA16(a0.y, b0.y, acc1); MFMA16(a0.z, b0.z, acc2); MFMA16(a0.w, b0.w, acc3);
         }
         if (n < N) {
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) epi(4 * q + r, n, (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]));
+            for (int r = 0; r < 4; ++r) v[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+            epi(4 * q, n, v);                       // rows 4q .. 4q+3 of column n
         }
     }
 }
@@ -115,11 +121,12 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
     // ---- issue every global load this kernel depends on, in one batch: weights, X tile, step counter, epsilon,
     // and the per-layer descriptors (kernel arguments live in memory: the first scalar load of each cache
     // line is a full memory round trip, so touch them all now instead of one per stage)
+    __shared__ FusedLayer slay[MAX_LAYERS];
     {
-        int warm = 0;
-#pragma unroll 1
-        for (int j = 0; j < NL; ++j) warm += a.lay[j].fi + a.lay[j].w_off;
-        asm volatile("" ::"s"(warm));
+        constexpr int NW = (int)(sizeof(FusedLayer) * MAX_LAYERS / sizeof(int));
+        const int* src = reinterpret_cast<const int*>(&a.lay[0]);
+        int* dstl = reinterpret_cast<int*>(&slay[0]);
+        for (int i = tid; i < NW; i += FTHREADS) dstl[i] = src[i];
     }
     const uint32_t step = a.st->step;
     float* xs = lds + a.lds_x;
@@ -158,17 +165,25 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
             lds_barrier();
         }
 #pragma unroll
-        for (int u = 0; u < STAGE_U; ++u) *reinterpret_cast<f32x4*>(lds + dst[u]) = v[u];
+        for (int u = 0; u < STAGE_U; ++u) {
+            float* d = lds + dst[u];                       // consecutive fan-out columns are 4 floats apart in the image
+            d[0] = v[u][0]; d[4] = v[u][1]; d[8] = v[u][2]; d[12] = v[u][3];
+        }
     }
+    // X tile into LDS, and its transposed copy XT[col][ldT] for the weight-gradient kernel (zeros on padded rows)
     if (x_small && ((a.D & 3) == 0)) {
-        if (tid < rows_here * xf4_per_row) {
+        if (tid < FTM * xf4_per_row) {
             const int r = tid / xf4_per_row, c4 = (tid - r * xf4_per_row) << 2;
             *reinterpret_cast<float4*>(xs + r * a.s_x + c4) = xv;
+            float* xt = a.XT + (long)c4 * a.ldT + r0 + r;
+            xt[0] = xv.x; xt[a.ldT] = xv.y; xt[2 * a.ldT] = xv.z; xt[3 * a.ldT] = xv.w;
         }
     } else {
-        for (int i = tid; i < rows_here * a.D; i += FTHREADS) {
+        for (int i = tid; i < FTM * a.D; i += FTHREADS) {
             const int r = i / a.D, cc = i - r * a.D;
-            xs[r * a.s_x + cc] = a.X[(long)(r0 + r) * a.ldx + cc];
+            const float xval = (r < rows_here) ? a.X[(long)(r0 + r) * a.ldx + cc] : 0.0f;
+            xs[r * a.s_x + cc] = xval;
+            a.XT[(long)cc * a.ldT + r0 + r] = xval;
         }
     }
     lds_barrier();
@@ -180,37 +195,53 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
     float* dnext = lds + a.lds_d1;
     float bce = 0.f, kl = 0.f;
 
+    // Descriptor fields are copied into locals at the top of each stage: read through `slay[l]` inside the
+    // epilogue they are re-fetched from the kernel-argument segment for every element.
+    const float lo = a.lo, hi = a.hi, inv_batch = a.inv_batch;
+    const int s_x = a.s_x, s_z = a.s_z, s_d = a.s_d;
+    const long ldT = a.ldT;
+
+    // Epilogues are branch-free over the lane's four rows: workspace rows are padded to a multiple of 16 so
+    // rows past the batch are computed and stored like the others (their dPre is forced to 0, nothing reads them).
     // ---- forward
     for (int l = 0; l < NL; ++l) {
-        const FusedLayer& y = a.lay[l];
-        const float* in = (l == 0) ? xs : (l == L + 1 ? zs : lds + a.lay[l - 1].lds_out);
-        const int sin = (l == 0) ? a.s_x : (l == L + 1 ? a.s_z : a.lay[l - 1].s_out);
-        const float* wimg = lds + y.lds_w;
-        const float* bias = lds + y.lds_b;
-        const int K16 = (y.fi + 15) & ~15;
+        const float* in = (l == 0) ? xs : (l == L + 1 ? zs : lds + slay[l - 1].lds_out);
+        const int sin = (l == 0) ? s_x : (l == L + 1 ? s_z : slay[l - 1].s_out);
+        const float* wimg = lds + slay[l].lds_w;
+        const float* bias = lds + slay[l].lds_b;                       // stride 4 (same interleave as the weights)
+        const int fi = slay[l].fi, fo = slay[l].fo, nn = slay[l].nn, act = slay[l].act;
+        const int K16 = (fi + 15) & ~15;
         if (l < NL - 1) {
-            float* o = lds + y.lds_out;
-            tile_gemm16<false>(in, sin, K16, wimg, y.s_w, y.fo, [&](int row, int col, float v) {
-                const float yv = act_fwd(y.act, v + bias[col]);                        // layer.py:368
-                o[row * y.s_out + col] = yv;
-                if (row < rows_here) y.out_g[(long)(r0 + row) * y.ld + col] = yv;
+            float* o = lds + slay[l].lds_out;
+            const int s_out = slay[l].s_out;
+            float* og = slay[l].out_g + r0;                                   // transposed: [col][ldT], rows contiguous
+            tile_gemm16<false>(in, sin, K16, wimg, nn, fo, [&](int row0, int col, float (&v)[4]) {
+                const float bcol = bias[4 * col];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bcol;
+                act_fwd4(act, v);                                                     // layer.py:368
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(row0 + r) * s_out + col] = v[r];
+                *reinterpret_cast<float4*>(og + (long)col * ldT + row0) = make_float4(v[0], v[1], v[2], v[3]);
             });
             STAMP_NS();
             lds_barrier();
             STAMP_NS();
             if (l == L) {
                 // z = mu + eps * exp(log_sigma)  (layer.py:279) and the KL row terms (_ae_utils.py:49)
+                float* zg = a.Zb_g + r0;                                      // transposed [Z][ldT]
                 for (int i = tid, u = 0; i < FTM * Z; i += FTHREADS, ++u) {
                     const int r = i / Z, k = i - r * Z;
+                    if (r >= rows_here) zg[(long)k * ldT + r] = 0.0f;          // finite filler for the padded rows
                     if (r < rows_here) {
-                        const float mu = o[r * y.s_out + k], ls = o[r * y.s_out + Z + k];
+                        const float mu = o[r * s_out + k], ls = o[r * s_out + Z + k];
                         float e;
                         if (a.eps_in) e = (u == 0) ? eps_pre[0] : (u == 1 ? eps_pre[1] : a.eps_in[(long)r0 * Z + i]);
                         else e = philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + r0 + r) * Z + k);
                         const float z = mu + e * expf(ls);
-                        zs[r * a.s_z + k] = z;
-                        es[r * a.s_z + k] = e;
-                        a.Zb_g[(long)(r0 + r) * a.ldz + k] = z;
+                        zs[r * s_z + k] = z;
+                        es[r * s_z + k] = e;
+                        zg[(long)k * ldT + r] = z;
                         kl += -0.5f * (1.0f + 2.0f * ls - mu * mu - expf(2.0f * ls));
                     }
                 }
@@ -218,19 +249,25 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
             }
         } else {
             // sigmoid output + clipped Bernoulli NLL + dL/dpre in one epilogue (layer.py:333-338, _ae_utils.py:31-32)
-            tile_gemm16<false>(in, sin, K16, wimg, y.s_w, y.fo, [&](int row, int col, float v) {
-                float d = 0.f;
-                if (row < rows_here) {
-                    const float p = 1.0f / (1.0f + expf(-(v + bias[col])));
-                    const float x = xs[row * a.s_x + col];
-                    const float pl = fmaxf(p, a.lo), pc = fminf(pl, a.hi), om = 1.0f - pc;
-                    bce -= x * logf(pc) + (1.0f - x) * logf(om);
-                    const bool pass = (p >= a.lo) && (pl <= a.hi);
-                    const float dp = pass ? -(x / pc - (1.0f - x) / om) * a.inv_batch : 0.0f;
-                    d = dp * p * (1.0f - p);
-                    y.dpre_g[(long)(r0 + row) * y.ld + col] = d;
+            float* dg = slay[l].dpre_g + r0;
+            tile_gemm16<false>(in, sin, K16, wimg, nn, fo, [&](int row0, int col, float (&v)[4]) {
+                const float bcol = bias[4 * col];
+                float dv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = (row0 + r) < rows_here;
+                    const float p = 1.0f / (1.0f + expf(-(v[r] + bcol)));
+                    const float x = xs[(row0 + r) * s_x + col];
+                    const float pl = fmaxf(p, lo), pc = fminf(pl, hi), om = 1.0f - pc;
+                    const float term = x * logf(pc) + (1.0f - x) * logf(om);
+                    bce -= valid ? term : 0.0f;
+                    const bool pass = valid && (p >= lo) && (pl <= hi);
+                    const float dp = pass ? -(x / pc - (1.0f - x) / om) * inv_batch : 0.0f;
+                    const float d = valid ? dp * p * (1.0f - p) : 0.0f;
+                    dv[r] = d;
+                    dcur[(row0 + r) * s_d + col] = d;
                 }
-                dcur[row * a.s_d + col] = d;
+                *reinterpret_cast<float4*>(dg + (long)col * ldT + row0) = make_float4(dv[0], dv[1], dv[2], dv[3]);
             });
             lds_barrier();
         }
@@ -239,46 +276,55 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
 
     // ---- backward through the activations: dcur holds dPre of layer l, [16 x fo_l] zero padded
     for (int l = NL - 1; l >= 1; --l) {
-        const FusedLayer& y = a.lay[l];
-        const float* wimg = lds + y.lds_w;
-        const int K16 = (y.fo + 15) & ~15;
+        const float* wimg = lds + slay[l].lds_w;
+        const int fi = slay[l].fi, nn = slay[l].nn;
+        const int K16 = (slay[l].fo + 15) & ~15;
+        const float* po = lds + slay[l - 1].lds_out;
+        const int p_sout = slay[l - 1].s_out, p_act = slay[l - 1].act;
+        float* pg = slay[l - 1].dpre_g + r0;
         if (l == L + 1) {
-            const FusedLayer& hd = a.lay[L];
-            const float* ml = lds + hd.lds_out;
-            tile_gemm16<true>(dcur, a.s_d, K16, wimg, y.s_w, y.fi, [&](int row, int col, float v) {
-                float g_mu = 0.f, g_ls = 0.f;
-                if (row < rows_here) {
-                    const float mu = ml[row * hd.s_out + col], ls = ml[row * hd.s_out + Z + col];
-                    const float e = es[row * a.s_z + col];
-                    const float dmu = v + mu * a.inv_batch;
-                    const float dls = v * e * expf(ls) + (expf(2.0f * ls) - 1.0f) * a.inv_batch;
-                    g_mu = act_bwd(hd.act, mu, dmu);
-                    g_ls = act_bwd(hd.act, ls, dls);
-                    hd.dpre_g[(long)(r0 + row) * hd.ld + col] = g_mu;
-                    hd.dpre_g[(long)(r0 + row) * hd.ld + Z + col] = g_ls;
+            // l - 1 == L: the fused heads.  v = dL/dz through the reparameterisation and the KL term.
+            tile_gemm16<true>(dcur, s_d, K16, wimg, nn, fi, [&](int row0, int col, float (&v)[4]) {
+                float mu[4], ls[4], g_mu[4], g_ls[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mu[r] = po[(row0 + r) * p_sout + col];
+                    ls[r] = po[(row0 + r) * p_sout + Z + col];
+                    const float e = es[(row0 + r) * s_z + col];
+                    g_mu[r] = v[r] + mu[r] * inv_batch;
+                    g_ls[r] = v[r] * e * expf(ls[r]) + (expf(2.0f * ls[r]) - 1.0f) * inv_batch;
                 }
-                dnext[row * a.s_d + col] = g_mu;
-                dnext[row * a.s_d + Z + col] = g_ls;
+                act_bwd4(p_act, mu, g_mu);
+                act_bwd4(p_act, ls, g_ls);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = (row0 + r) < rows_here;
+                    g_mu[r] = valid ? g_mu[r] : 0.0f;
+                    g_ls[r] = valid ? g_ls[r] : 0.0f;
+                    dnext[(row0 + r) * s_d + col] = g_mu[r];
+                    dnext[(row0 + r) * s_d + Z + col] = g_ls[r];
+                }
+                *reinterpret_cast<float4*>(pg + (long)col * ldT + row0) = make_float4(g_mu[0], g_mu[1], g_mu[2], g_mu[3]);
+                *reinterpret_cast<float4*>(pg + (long)(Z + col) * ldT + row0) = make_float4(g_ls[0], g_ls[1], g_ls[2], g_ls[3]);
             });
         } else {
-            const FusedLayer& pv = a.lay[l - 1];
-            const float* po = lds + pv.lds_out;
-            tile_gemm16<true>(dcur, a.s_d, K16, wimg, y.s_w, y.fi, [&](int row, int col, float v) {
-                float g = 0.f;
-                if (row < rows_here) {
-                    g = act_bwd(pv.act, po[row * pv.s_out + col], v);
-                    pv.dpre_g[(long)(r0 + row) * pv.ld + col] = g;
-                }
-                dnext[row * a.s_d + col] = g;
+            tile_gemm16<true>(dcur, s_d, K16, wimg, nn, fi, [&](int row0, int col, float (&v)[4]) {
+                float yv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yv[r] = po[(row0 + r) * p_sout + col];
+                act_bwd4(p_act, yv, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dnext[(row0 + r) * s_d + col] = v[r];
+                *reinterpret_cast<float4*>(pg + (long)col * ldT + row0) = make_float4(v[0], v[1], v[2], v[3]);
             });
         }
         // the next stage reads k up to rup16(width just written): clear the tail this stage did not write
         {
-            const int wrote = (l == L + 1) ? 2 * Z : y.fi;
+            const int wrote = (l == L + 1) ? 2 * Z : fi;
             const int tail = ((wrote + 15) & ~15) - wrote;
             for (int i = tid; i < FTM * tail; i += FTHREADS) {
                 const int r = i / tail;
-                dnext[r * a.s_d + wrote + (i - r * tail)] = 0.f;
+                dnext[r * s_d + wrote + (i - r * tail)] = 0.f;
             }
         }
         lds_barrier();
@@ -334,6 +380,12 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, q = lane >> 4;
+#ifdef SMRT_STAMPS
+#define BST(i) do { if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[i] = wall_clock64(); } while (0)
+#else
+#define BST(i) do { } while (0)
+#endif
+    BST(20);
     const int t = blockIdx.x * 4 + wave;
     const bool live = t < a.total_tiles;
     const int tt = live ? t : a.total_tiles - 1;           // idle waves shadow the last tile and store nothing
@@ -366,34 +418,44 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
     float alpha = 0.f;
     if (a.opt == 2) alpha = a.lr * sqrtf(1.0f - a.st->b2pow) / (1.0f - a.st->b1pow);
 
-    // ---- [X | 1]^T . dPre over all rows: 64 rows (4 k-blocks) per batch of loads
-    const int m = m0 + c, mm = min(m, fi - 1);               // A operand: output row m (input feature)
-    const int n = n0 + c, nn = min(n, fo - 1);               // B operand: output col n
-    const float* Ap = Ly.A + mm;
-    const float* Bp = Ly.B + nn;
+    BST(21);
+    // ---- [X | 1]^T . dPre over all rows.  Both operands are stored TRANSPOSED ([feature][row], rows contiguous)
+    // by the forward/backward kernel, so a lane's four k values are one 16-byte load; rows past the batch hold
+    // dPre = 0 (and finite activations), so no k masking is needed up to rup16(rows).
+    const int m = m0 + c, mm = min(m, fi - 1);                // A operand: output row m (input feature); m == fi -> ones
+    const int n = n0 + c, nn = min(n, fo - 1);                // B operand: output col n
+    const float* Ap = Ly.A + (long)mm * a.ldT + 4 * q;
+    const float* Bp = Ly.B + (long)nn * a.ldT + 4 * q;
+    const bool ones = (m == fi);
+    const int rows16 = (rows + 15) & ~15;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    for (int k0 = 0; k0 < rows; k0 += 128) {                 // 128 rows (8 k-blocks, 64 loads per lane) per batch
-        float av[8][4], bv[8][4];
+    for (int k0 = 0; k0 < rows16; k0 += 128) {               // 128 rows (8 k-blocks, 16 loads per lane) per batch
+        f32x4 av[8], bv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 8; ++j) {
+            const int k = min(k0 + 16 * j, rows16 - 16);      // clamped + unconditional
+            av[j] = *reinterpret_cast<const f32x4*>(Ap + k);
+            bv[j] = *reinterpret_cast<const f32x4*>(Bp + k);
+        }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k = k0 + 16 * j + 4 * q + s, kk = min(k, rows - 1);
-                const float x = Ap[(long)kk * Ly.lda];
-                const float d = Bp[(long)kk * Ly.ldb];
-                const bool kin = k < rows;
-                av[j][s] = (kin && m < fi) ? x : ((kin && m == fi) ? 1.0f : 0.0f);     // virtual ones column -> db
-                bv[j][s] = (kin && n < fo) ? d : 0.0f;
+        for (int j = 0; j < 8; ++j) {
+            const bool kin = (k0 + 16 * j) < rows16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                av[j][e] = ones ? 1.0f : av[j][e];            // virtual ones column -> bias gradient
+                bv[j][e] = kin ? bv[j][e] : 0.0f;
             }
+        }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                MFMA16(av[4 * jj + 0][s], bv[4 * jj + 0][s], acc0); MFMA16(av[4 * jj + 1][s], bv[4 * jj + 1][s], acc1);
-                MFMA16(av[4 * jj + 2][s], bv[4 * jj + 2][s], acc2); MFMA16(av[4 * jj + 3][s], bv[4 * jj + 3][s], acc3);
+            for (int e = 0; e < 4; ++e) {
+                MFMA16(av[4 * jj + 0][e], bv[4 * jj + 0][e], acc0); MFMA16(av[4 * jj + 1][e], bv[4 * jj + 1][e], acc1);
+                MFMA16(av[4 * jj + 2][e], bv[4 * jj + 2][e], acc2); MFMA16(av[4 * jj + 3][e], bv[4 * jj + 3][e], acc3);
             }
     }
 
+    BST(22);
     // ---- epilogue: L2, dropout backward, value clip, optimizer (base.py:127-149)
     float l2acc = 0.f;
 #pragma unroll
@@ -413,6 +475,7 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
             if (has_s1) a.s1[idx[r]] = s1[r];
         }
     }
+    BST(23);
     const float tot = block_sum_256(l2acc, red);            // __syncthreads inside: every lane's st reads are done
     if (tid == 0) {
         a.l2_partials[blockIdx.x] = tot;
@@ -425,6 +488,7 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
             *a.ticket = 0u;
         }
     }
+    BST(24);
 }
 
 int dw_opt_blocks(int total_tiles) { return (total_tiles + 3) / 4; }

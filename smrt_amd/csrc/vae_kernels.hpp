@@ -94,12 +94,12 @@ struct FinalizeArgs {
 struct FusedLayer {
     const float* W;       // augmented weights in use (post-dropout when dropout < 1)
     const float* bias;
-    float* out_g;         // layer output [rows][ld] (null for the last decoder layer)
-    float* dpre_g;        // dL/dpre      [rows][ld]
+    float* out_g;         // layer output, TRANSPOSED [rup16(fo)][ldT] (null for the last decoder layer)
+    float* dpre_g;        // dL/dpre,      TRANSPOSED [rup16(fo)][ldT]
     int fi, fo, ld, act;
     int lds_out, s_out;   // LDS offset / row stride of the layer output tile (floats)
-    int lds_w, s_w;       // LDS offset / row stride of the zero-padded weight image [rup16(fi)][s_w]
-    int lds_b;            // LDS offset of the bias vector [rup16(fo)]
+    int lds_w, nn;        // LDS offset of the k-quad interleaved weight image [rup16(fi)/4][nn][4], nn = rup16(fo)+1
+    int lds_b;            // LDS offset of the bias vector, stride 4: b[col] at lds_b + 4*col
     int w_off;            // offset of this layer's augmented matrix inside the flat parameter buffer (floats)
 };
 struct FusedArgs {
@@ -109,7 +109,9 @@ struct FusedArgs {
     const float* Wflat; int w_total;      // flat parameter buffer in use (post-dropout when dropout < 1)
     const int* stage_tab;                 // [w_total / 4] LDS float offset of every 16-byte piece of Wflat
     const float* eps_in;
-    float* Zb_g; long ldz;
+    float* Zb_g;          // z, TRANSPOSED [rup16(Z)][ldT]
+    float* XT;            // X tile copy, TRANSPOSED [rup16(D)][ldT]
+    long ldT;             // row capacity of the transposed workspace (multiple of 16)
     int lds_x, s_x, lds_z, lds_e, s_z, lds_d0, lds_d1, s_d, lds_total;
     uint64_t seed; const DevState* st; long row0_global;
     float lo, hi, inv_batch;
@@ -120,21 +122,23 @@ void launch_fused_fwd_bwd(hipStream_t s, const FusedArgs& a);
 
 // dW + optimizer fused (fused_small.hip)
 struct DwOptLayer {
-    const float* A;      // layer input [rows][lda]
-    const float* B;      // dPre        [rows][ldb]
-    long lda, ldb, off;  // off: start of the layer's augmented matrix in the flat parameter buffer
+    const float* A;      // layer input, TRANSPOSED [feature][ldT]
+    const float* B;      // dPre,        TRANSPOSED [feature][ldT]
+    long off;            // start of the layer's augmented matrix in the flat parameter buffer
     int fi, fo, ld, l2;
     int tiles_n, tile_begin;
 };
 struct DwOptArgs {
     DwOptLayer L[MAX_LAYERS];
     int n_layers, total_tiles, rows;
+    long ldT;
     float* W; const float* Wd; const float* mask;
     float* s0; float* s1;
     float* grad_out;
     float* l2_partials;
     DevState* st;
     unsigned* ticket;
+    unsigned long long* dbg;   // B: diagnostic builds only (-DSMRT_STAMPS)
     int opt, clip, has_drop, has_l2;
     float lr, l2, gmin, gmax, keep;
 };
