@@ -103,6 +103,17 @@ int64_t smrt_vae_dp_count(const smrt_vae* h);
 int  smrt_vae_grad_step(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t rows, int64_t global_rows,
                         int64_t row0_global, const float* eps_dev, float* grads_dev);
 int  smrt_vae_apply_grads(smrt_vae* h, const float* grads_dev, float* cost_host);
+/* The same two halves, enqueued only ("async": no host synchronisation, no read-back), so that a
+ * host loop of grad_step -> all-reduce -> apply_grads never stalls the GPU.  rows == 0 is allowed (a rank
+ * whose stripe of a ragged tail batch is empty): grads_dev is zero-filled.  cost_dev: one device float that
+ * receives the step's cost, or NULL. */
+int  smrt_vae_grad_step_async(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t rows, int64_t global_rows,
+                              int64_t row0_global, const float* eps_dev, float* grads_dev);
+int  smrt_vae_apply_grads_async(smrt_vae* h, const float* grads_dev, float* cost_dev);
+/* Lend the handle a stream (no reference counterpart).  own == 0: every later call enqueues on hip_stream
+ * (a hipStream_t; NULL is the legacy default stream), e.g. the stream the caller's RCCL collectives are ordered
+ * against; own != 0: back to the handle's private stream.  Synchronises the stream in use first. */
+int  smrt_vae_set_stream(smrt_vae* h, void* hip_stream, int32_t own);
 
 /* sess.run([z_mean_, z_log_sigma_], {X}) (autoencoder.py:500).  mu/ls are [n][n_latent] contiguous. */
 int  smrt_vae_encode(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n, float* mu_dev, float* logsig_dev);

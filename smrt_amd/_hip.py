@@ -24,7 +24,8 @@ EXPORTS = [
     "smrt_vae_create", "smrt_vae_destroy", "smrt_vae_param_count", "smrt_vae_set_params",
     "smrt_vae_get_params", "smrt_vae_get_opt_state", "smrt_vae_reset_opt_state", "smrt_vae_step_count",
     "smrt_vae_set_dropout_masks", "smrt_vae_train_step", "smrt_vae_train_epochs", "smrt_vae_dp_count",
-    "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_encode", "smrt_vae_decode",
+    "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
+    "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
     "smrt_last_error", "smrt_version",
 ]
@@ -81,6 +82,9 @@ def load():
     lib.smrt_vae_train_epochs.argtypes = [vp, vp, i64, i64, i32, i32, i32, C.c_float, f32p, f32p, C.POINTER(i32)]
     lib.smrt_vae_grad_step.argtypes = [vp, vp, i64, i32, i64, i64, vp, vp]
     lib.smrt_vae_apply_grads.argtypes = [vp, vp, f32p]
+    lib.smrt_vae_grad_step_async.argtypes = [vp, vp, i64, i32, i64, i64, vp, vp]
+    lib.smrt_vae_apply_grads_async.argtypes = [vp, vp, vp]
+    lib.smrt_vae_set_stream.argtypes = [vp, vp, i32]
     lib.smrt_vae_encode.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.smrt_vae_decode.argtypes = [vp, vp, i64, i64, vp, i64]
     lib.smrt_vae_generate.argtypes = [vp, i64, C.c_uint64, C.c_float, C.c_float, vp, i64]
@@ -274,6 +278,34 @@ class VaeHandle(object):
         cost = C.c_float()
         _check(self._lib.smrt_vae_apply_grads(self._live(), grads_tensor.data_ptr(), C.byref(cost)), "smrt_vae_apply_grads")
         return np.float32(cost.value)
+
+    def use_stream(self, torch_stream=None):
+        """Enqueue on ``torch_stream`` (a ``torch.cuda.Stream``) from now on; ``None`` returns to the private stream."""
+        if torch_stream is None:
+            _check(self._lib.smrt_vae_set_stream(self._live(), None, 1), "smrt_vae_set_stream")
+        else:
+            _check(self._lib.smrt_vae_set_stream(self._live(), C.c_void_p(torch_stream.cuda_stream), 0),
+                   "smrt_vae_set_stream")
+
+    def grad_step_async(self, X_ptr, ldx, rows, global_rows, row0_global, grads_tensor):
+        """Raw-pointer form for host loops: no synchronisation, Philox epsilon by global row."""
+        _check(self._lib.smrt_vae_grad_step_async(self._live(), X_ptr, int(ldx), int(rows), int(global_rows),
+                                                  int(row0_global), None, grads_tensor.data_ptr()),
+               "smrt_vae_grad_step_async")
+
+    def apply_grads_async(self, grads_tensor, cost_tensor=None):
+        _check(self._lib.smrt_vae_apply_grads_async(self._live(), grads_tensor.data_ptr(),
+                                                    None if cost_tensor is None else cost_tensor.data_ptr()),
+               "smrt_vae_apply_grads_async")
+
+    def dp_grad_step(self, X_local, row_offset, rows, global_rows, row0_global, grads_tensor):
+        """Stripe ``[row_offset, row_offset + rows)`` of the rank-local matrix ``X_local = (tensor, ld)``."""
+        Xt, ldx = X_local
+        self.grad_step_async(Xt.data_ptr() + 4 * int(row_offset) * int(ldx), ldx, rows, global_rows, row0_global,
+                             grads_tensor)
+
+    def dp_apply(self, grads_tensor, cost_tensor=None):
+        self.apply_grads_async(grads_tensor, cost_tensor)
 
     # -- inference
     def encode(self, X, to_host=True):

@@ -20,6 +20,7 @@ from sklearn.utils.validation import check_array, check_is_fitted
 
 from .. import _hip
 from ..utils import DEFAULT_DROPOUT, DEFAULT_L2, NPDTYPE, get_random_state, validate_float
+from .data_parallel import DataParallelTrainer, dist_info, local_row_index
 from .topography import VAETopography
 
 __all__ = ["VariationalAutoEncoder", "PERMITTED_ACTIVATIONS", "PERMITTED_OPTIMIZERS"]
@@ -85,8 +86,11 @@ class VariationalAutoEncoder(BaseEstimator, TransformerMixin):
     (0, 1) meaning a fraction of the input width) are required.
 
     Additional, optional hooks (not in the reference): ``set_initial_weights`` /
-    ``get_weights`` / ``set_weights`` for checkpointing and parity injection, and the ``device``
-    attribute (GPU ordinal, default: current torch device).
+    ``get_weights`` / ``set_weights`` for checkpointing and parity injection, the ``device``
+    attribute (GPU ordinal, default: current torch device), and the ``data_parallel`` attribute: when it is
+    true and ``torch.distributed`` is initialised with more than one rank, ``fit`` (called by EVERY rank with
+    the same ``X``) trains one replicated model on row stripes of each mini-batch with a gradient all-reduce
+    per step (``smrt_amd.autoencode.data_parallel``); the fitted estimators are identical on all ranks.
     """
 
     def __init__(self, n_hidden, n_latent_factors, activation_function="sigmoid", learning_rate=0.05,
@@ -197,10 +201,19 @@ class VariationalAutoEncoder(BaseEstimator, TransformerMixin):
         if batch_size < 1:
             raise ValueError("batch_size must be >= 1")
 
-        X_dev = _hip.to_device_padded(X, sess.device)             # fp64 -> fp32 feed cast, once (base.py:174)
-        costs, ms = sess.train_epochs(X_dev, batch_size, self.n_epochs, early_stopping=bool(self.early_stopping),
-                                      min_change=self.min_change)
-        epoch_times = [float(t) / 1e3 for t in ms]
+        rank, world, dist = dist_info()
+        if getattr(self, "data_parallel", False) and world > 1:
+            # one replicated model, each rank keeps only its stripes of every mini-batch in HBM
+            idx = local_row_index(n_samples, batch_size, world, rank)
+            X_dev = _hip.to_device_padded(X[idx], sess.device)
+            trainer = DataParallelTrainer(sess, X_dev, n_samples, batch_size, rank, world, dist)
+            costs, epoch_times = trainer.run_epochs(self.n_epochs, early_stopping=bool(self.early_stopping),
+                                                    min_change=self.min_change)
+        else:
+            X_dev = _hip.to_device_padded(X, sess.device)         # fp64 -> fp32 feed cast, once (base.py:174)
+            costs, ms = sess.train_epochs(X_dev, batch_size, self.n_epochs, early_stopping=bool(self.early_stopping),
+                                          min_change=self.min_change)
+            epoch_times = [float(t) / 1e3 for t in ms]
         for epoch, (c, t) in enumerate(zip(costs, epoch_times)):
             if epoch % self.display_step == 0 and self.verbose > 1:
                 print("Epoch: %i, cost=%.6f, time=%.4f (sec)" % (epoch + 1, c, t))

@@ -29,7 +29,8 @@ struct LayerI { int fi, fo, ld; long off; int act; int l2; };
 struct smrt_vae {
     smrt_vae_cfg cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // stream in use (own_stream unless the caller lent one)
+    hipStream_t own_stream = nullptr;
     int L = 0, NL = 0, Z = 0, D = 0;
     LayerI lay[MAX_LAYERS];
     long P_int = 0, P_abi = 0;
@@ -497,7 +498,8 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
     const char* g = std::getenv("SMRT_HIP_GRAPH");
     h->use_graph = g ? std::atoi(g) : 1;
     auto bail = [&](int rc) { smrt_vae_destroy(h); return rc; };
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(-2, "hipStreamCreate failed"));
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(-2, "hipStreamCreate failed"));
+    h->stream = h->own_stream;
     int rc;
     if ((rc = dalloc(&h->W, (size_t)h->P_int))) return bail(rc);
     if ((rc = dalloc(&h->s0, (size_t)h->P_int))) return bail(rc);
@@ -535,7 +537,7 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
 void smrt_vae_destroy(smrt_vae* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream || h->own_stream) (void)hipStreamSynchronize(h->stream);
     float** bufs[] = {&h->W, &h->Wd, &h->mask, &h->s0, &h->s1, &h->G, &h->gtmp, &h->Zb, &h->Eb, &h->bce_p, &h->kl_p,
                       &h->l2_p, &h->cost_dev, &h->ibuf[0], &h->ibuf[1], &h->izb};
     for (float** b : bufs) if (*b) (void)hipFree(*b);
@@ -552,7 +554,7 @@ void smrt_vae_destroy(smrt_vae* h) {
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     drop_graph(h);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 
@@ -694,7 +696,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     // A captured graph replays the identical epoch: every step-dependent scalar (Philox step, Adam powers)
     // lives in device memory, so only the cost slot differs -> the graph writes slot 0 and a copy node moves it.
     bool graphed = false;
-    if (h->use_graph && !h->prof && n_epochs > 1) {
+    if (h->use_graph && !h->prof && n_epochs > 1 && h->stream == h->own_stream) {
         const bool hit = h->gexec && h->g_X == X_dev && h->g_ldx == ldx && h->g_n == n_rows && h->g_batch == batch_size;
         if (hit) graphed = true;
         else {
@@ -751,27 +753,49 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     return 0;
 }
 
-int smrt_vae_grad_step(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t rows, int64_t global_rows,
-                       int64_t row0_global, const float* eps_dev, float* grads_dev) {
-    if (!h || !grads_dev) return fail(-1, "smrt_vae_grad_step: null argument");
-    if (rows < 1 || global_rows < rows) return fail(-1, "smrt_vae_grad_step: bad row counts");
-    if (h->has_drop) return fail(-1, "smrt_vae_grad_step: dropout < 1 is not supported on the data-parallel path");
-    TRY(check_mat(X_dev, ldx, h->D, "smrt_vae_grad_step: X"));
-    if (((uintptr_t)grads_dev & 15) != 0) return fail(-1, "smrt_vae_grad_step: grads_dev must be 16-byte aligned");
+int smrt_vae_set_stream(smrt_vae* h, void* hip_stream, int32_t own) {
+    if (!h) return fail(-1, "smrt_vae_set_stream: null handle");
     HIPC(hipSetDevice(h->device));
-    TRY(ensure_train(h, rows));
-    StepOut o{nullptr, nullptr, grads_dev};
-    TRY(enqueue_step(h, X_dev, ldx, rows, 1.0f / (float)global_rows, row0_global, eps_dev, 1, o));
-    HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(h->stream));
+    drop_graph(h);
+    h->stream = own ? h->own_stream : (hipStream_t)hip_stream;
     return 0;
 }
 
-int smrt_vae_apply_grads(smrt_vae* h, const float* grads_dev, float* cost_host) {
-    if (!h || !grads_dev) return fail(-1, "smrt_vae_apply_grads: null argument");
-    if (((uintptr_t)grads_dev & 15) != 0) return fail(-1, "smrt_vae_apply_grads: grads_dev must be 16-byte aligned");
+static int grad_step_impl(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t rows, int64_t global_rows,
+                          int64_t row0_global, const float* eps_dev, float* grads_dev, bool sync, const char* who) {
+    if (!h || !grads_dev) return fail(-1, std::string(who) + ": null argument");
+    if (rows < 0 || global_rows < rows || global_rows < 1) return fail(-1, std::string(who) + ": bad row counts");
+    if (h->has_drop) return fail(-1, std::string(who) + ": dropout < 1 is not supported on the data-parallel path");
+    if (((uintptr_t)grads_dev & 15) != 0) return fail(-1, std::string(who) + ": grads_dev must be 16-byte aligned");
     HIPC(hipSetDevice(h->device));
-    TRY(ensure_cost(h, 1));
+    if (rows == 0) {
+        // a rank whose stripe of a ragged tail batch is empty contributes zeros to the all-reduce
+        HIPC(hipMemsetAsync(grads_dev, 0, sizeof(float) * (size_t)(h->P_int + 4), h->stream));
+    } else {
+        TRY(check_mat(X_dev, ldx, h->D, who));
+        TRY(ensure_train(h, rows));
+        StepOut o{nullptr, nullptr, grads_dev};
+        TRY(enqueue_step(h, X_dev, ldx, rows, 1.0f / (float)global_rows, row0_global, eps_dev, 1, o));
+        HIPC(hipGetLastError());
+    }
+    if (sync) HIPC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int smrt_vae_grad_step(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t rows, int64_t global_rows,
+                       int64_t row0_global, const float* eps_dev, float* grads_dev) {
+    return grad_step_impl(h, X_dev, ldx, rows, global_rows, row0_global, eps_dev, grads_dev, true, "smrt_vae_grad_step");
+}
+
+int smrt_vae_grad_step_async(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t rows, int64_t global_rows,
+                             int64_t row0_global, const float* eps_dev, float* grads_dev) {
+    return grad_step_impl(h, X_dev, ldx, rows, global_rows, row0_global, eps_dev, grads_dev, false,
+                          "smrt_vae_grad_step_async");
+}
+
+// L2 + clip + optimizer on an already reduced gradient; the step's cost goes to cost_dst (device memory).
+static int enqueue_apply(smrt_vae* h, const float* grads_dev, float* cost_dst) {
     OptSeg segs[MAX_LAYERS];
     fill_segs(h, segs);
     OptArgs p{};
@@ -784,13 +808,32 @@ int smrt_vae_apply_grads(smrt_vae* h, const float* grads_dev, float* cost_host) 
     launch_optimizer(h->stream, p, nullptr);
     FinalizeArgs f{};
     f.l2p = h->l2_p; f.n_l2 = h->n_l2; f.presummed = grads_dev + h->P_int; f.l2 = p.l2;
-    f.cost_out = h->cost_dev; f.st = h->st; f.advance = 1;
+    f.cost_out = cost_dst; f.st = h->st; f.advance = 1;
     launch_finalize(h->stream, f);
     HIPC(hipGetLastError());
+    return 0;
+}
+
+int smrt_vae_apply_grads(smrt_vae* h, const float* grads_dev, float* cost_host) {
+    if (!h || !grads_dev) return fail(-1, "smrt_vae_apply_grads: null argument");
+    if (((uintptr_t)grads_dev & 15) != 0) return fail(-1, "smrt_vae_apply_grads: grads_dev must be 16-byte aligned");
+    HIPC(hipSetDevice(h->device));
+    TRY(ensure_cost(h, 1));
+    TRY(enqueue_apply(h, grads_dev, h->cost_dev));
     HIPC(hipMemcpyAsync(h->cost_pin, h->cost_dev, sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPC(hipStreamSynchronize(h->stream));
     h->steps += 1;
     if (cost_host) *cost_host = h->cost_pin[0];
+    return 0;
+}
+
+int smrt_vae_apply_grads_async(smrt_vae* h, const float* grads_dev, float* cost_dev) {
+    if (!h || !grads_dev) return fail(-1, "smrt_vae_apply_grads_async: null argument");
+    if (((uintptr_t)grads_dev & 15) != 0) return fail(-1, "smrt_vae_apply_grads_async: grads_dev must be 16-byte aligned");
+    HIPC(hipSetDevice(h->device));
+    TRY(ensure_cost(h, 1));
+    TRY(enqueue_apply(h, grads_dev, cost_dev ? cost_dev : h->cost_dev + 1));
+    h->steps += 1;
     return 0;
 }
 
