@@ -24,6 +24,11 @@ static int fail(int code, const std::string& m) { g_err = m; return code; }
 
 static inline int rup4(int v) { return (v + 3) & ~3; }
 
+// One device allocation carved into 256-byte aligned pieces.  Everything a training step touches sits in two
+// arenas (parameters; per-batch workspace), each a multiple of 2 MiB: a short kernel then needs a couple of
+// address translations instead of one per buffer -- in these few-microsecond launches a cold translation costs
+// more than the arithmetic.
+struct Arena { char* base = nullptr; size_t cap = 0, off = 0; };
 struct LayerI { int fi, fo, ld; long off; int act; int l2; };
 
 struct smrt_vae {
@@ -37,6 +42,7 @@ struct smrt_vae {
     int maxld = 0;
     bool has_drop = false, has_l2 = false, masks_injected = false;
 
+    Arena pa, ta;                        // parameter arena, training-workspace arena
     float *W = nullptr, *Wd = nullptr, *mask = nullptr, *s0 = nullptr, *s1 = nullptr;
     float *G = nullptr, *gtmp = nullptr;
     int g_splits_cap = 0;
@@ -71,9 +77,13 @@ struct smrt_vae {
     // row-tile fused forward/backward (small nets): LDS plan
     bool fused = false;
     FusedArgs fplan{};
+    FusedLayer flay[MAX_LAYERS];
     unsigned* ticket = nullptr;
     int tiles16 = 0;
-    int* stage_tab = nullptr;
+    int* stage_tab = nullptr;        // image float offset of every 16-byte piece of the flat parameter buffer
+    float* Wimg = nullptr;           // LDS-image twin of the parameters (fplan.img_total floats)
+    bool img_valid = false;          // Wimg matches W (kept current by the fused optimizer epilogue)
+    DwTile* tile_tab = nullptr;      // per-tile records of the fused dW + optimizer kernel
 
     // per-kernel profiling (eager launches bracketed by events)
     bool prof = false;
@@ -177,25 +187,31 @@ static void fill_segs(const smrt_vae* h, OptSeg* seg) {
 static inline int rup16(int v) { return (v + 15) & ~15; }
 
 // LDS plan of the fused row-tile kernel; h->fused says whether the net is small enough to use it.
+// The weight / bias images of all layers come first and contiguous (they are filled by one straight LDS-DMA copy of
+// the device-resident image twin), the activation tiles follow.
 static void plan_fused(smrt_vae* h) {
     FusedArgs& f = h->fplan;
     f = FusedArgs{};
     f.NL = h->NL; f.L = h->L; f.Z = h->Z; f.D = h->D;
     int off = 0, maxw = rup16(h->D);
-    f.s_x = rup16(h->D) + 4; f.lds_x = off; off += 16 * f.s_x;
     for (int l = 0; l < h->NL; ++l) {
         const LayerI& y = h->lay[l];
-        FusedLayer& q = f.lay[l];
+        FusedLayer& q = h->flay[l];
         q.fi = y.fi; q.fo = y.fo; q.ld = y.ld; q.act = y.act; q.w_off = (int)y.off;
         maxw = std::max(maxw, std::max(rup16(y.fo), rup16(y.fi)));
-        if (l < h->NL - 1) { q.s_out = rup16(y.fo) + 4; q.lds_out = off; off += 16 * q.s_out; }
         q.nn = rup16(y.fo) + 1; q.lds_w = off; off += (rup16(y.fi) / 4) * q.nn * 4;
         q.lds_b = off; off += 4 * rup16(y.fo);
+    }
+    f.img_total = (off + 255) & ~255;                  // whole 1 KiB wave-instructions
+    off = f.img_total;
+    f.s_x = rup16(h->D) + 4; f.lds_x = off; off += 16 * f.s_x;
+    for (int l = 0; l < h->NL - 1; ++l) {
+        FusedLayer& q = h->flay[l];
+        q.s_out = rup16(h->lay[l].fo) + 4; q.lds_out = off; off += 16 * q.s_out;
     }
     f.s_z = rup16(h->Z) + 4; f.lds_z = off; off += 16 * f.s_z; f.lds_e = off; off += 16 * f.s_z;
     f.s_d = maxw + 4; f.lds_d0 = off; off += 16 * f.s_d; f.lds_d1 = off; off += 16 * f.s_d;
     f.lds_total = off;
-    f.w_total = (int)h->P_int;
     h->tiles16 = 0;
     for (int l = 0; l < h->NL; ++l) h->tiles16 += ((h->lay[l].fi + 1 + 15) / 16) * ((h->lay[l].fo + 15) / 16);
     const char* e = std::getenv("SMRT_HIP_FUSED");
@@ -218,6 +234,21 @@ template <class T> static int dalloc(T** p, size_t n_elems) {
 }
 #define TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
 
+template <class T> static void carve(Arena& a, T** p, size_t n_elems) {
+    *p = (n_elems && a.base) ? reinterpret_cast<T*>(a.base + a.off) : nullptr;
+    a.off += (n_elems * sizeof(T) + 255) & ~size_t(255);
+}
+static int arena_alloc(Arena& a, size_t bytes) {
+    if (a.base) { (void)hipFree(a.base); a.base = nullptr; }
+    a.cap = (bytes + (2u << 20) - 1) & ~size_t((2u << 20) - 1);
+    hipError_t e = hipMalloc((void**)&a.base, a.cap);
+    if (e != hipSuccess) { a.base = nullptr; return fail(-3, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    e = hipMemset(a.base, 0, a.cap);
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // the handle's stream is non-blocking: make the zero-fill visible to it
+    if (e != hipSuccess) return fail(-3, std::string("arena zero-fill: ") + hipGetErrorString(e));
+    return 0;
+}
+
 // ------------------------------------------------------------------ dW tiling / split-K policy
 static int dw_tiles(const smrt_vae* h, int t) {
     int tot = 0;
@@ -235,32 +266,56 @@ static int choose_splits(const smrt_vae* h, int rows) {
 
 static int ensure_train(smrt_vae* h, int rows) {
     const int splits = choose_splits(h, rows);
-    if (splits > h->g_splits_cap) {
-        drop_graph(h);
-        TRY(dalloc(&h->G, (size_t)splits * h->P_int));
-        h->g_splits_cap = splits;
-    }
-    if (rows <= h->cap_rows) return 0;
+    if (splits <= h->g_splits_cap && rows <= h->cap_rows) return 0;
     drop_graph(h);
-    int cap = (std::max(rows, (int)h->cfg.max_batch) + 15) & ~15;     // fused kernels store whole 16-row tiles
-    for (int l = 0; l < h->NL; ++l) {
-        if (l < h->NL - 1) TRY(dalloc(&h->out[l], (size_t)cap * h->lay[l].ld));
-        TRY(dalloc(&h->dpre[l], (size_t)cap * h->lay[l].ld));
-    }
-    if (h->fused) {
-        for (int l = 0; l < h->NL; ++l) {
-            if (l < h->NL - 1) TRY(dalloc(&h->outT[l], (size_t)cap * rup16(h->lay[l].fo)));
-            TRY(dalloc(&h->dpreT[l], (size_t)cap * rup16(h->lay[l].fo)));
-        }
-        TRY(dalloc(&h->XT, (size_t)cap * rup16(h->D)));
-        TRY(dalloc(&h->ZT, (size_t)cap * rup16(h->Z)));
-    }
-    TRY(dalloc(&h->Zb, (size_t)cap * rup4(h->Z)));
-    TRY(dalloc(&h->Eb, (size_t)cap * rup4(h->Z)));
+    HIPC(hipStreamSynchronize(h->stream));
+    const int nsplit = std::max(splits, h->g_splits_cap);
+    const int cap = (std::max(std::max(rows, h->cap_rows), (int)h->cfg.max_batch) + 15) & ~15;   // fused kernels store whole 16-row tiles
     const int nb = std::max(((cap + 63) / 64) * ((h->D + 63) / 64), (cap + 15) / 16);
-    TRY(dalloc(&h->bce_p, (size_t)nb));
-    TRY(dalloc(&h->kl_p, (size_t)std::max(reparam_blocks(cap, h->Z), (cap + 15) / 16)));
+    auto layout = [&](Arena& a) {
+        a.off = 0;
+        carve(a, &h->G, (size_t)nsplit * h->P_int);
+        for (int l = 0; l < h->NL; ++l) {
+            carve(a, &h->out[l], (l < h->NL - 1) ? (size_t)cap * h->lay[l].ld : 0);
+            carve(a, &h->dpre[l], (size_t)cap * h->lay[l].ld);
+        }
+        carve(a, &h->Zb, (size_t)cap * rup4(h->Z));
+        carve(a, &h->Eb, (size_t)cap * rup4(h->Z));
+        carve(a, &h->bce_p, (size_t)nb);
+        carve(a, &h->kl_p, (size_t)std::max(reparam_blocks(cap, h->Z), (cap + 15) / 16));
+        if (h->fused) {
+            for (int l = 0; l < h->NL; ++l) {
+                carve(a, &h->outT[l], (l < h->NL - 1) ? (size_t)cap * rup16(h->lay[l].fo) : 0);
+                carve(a, &h->dpreT[l], (size_t)cap * rup16(h->lay[l].fo));
+            }
+            carve(a, &h->XT, (size_t)cap * rup16(h->D));
+            carve(a, &h->ZT, (size_t)cap * rup16(h->Z));
+            carve(a, &h->tile_tab, (size_t)h->tiles16);
+        }
+    };
+    Arena dry;
+    layout(dry);
+    TRY(arena_alloc(h->ta, dry.off));
+    layout(h->ta);
+    h->g_splits_cap = nsplit;
     h->cap_rows = cap;
+    if (h->fused) {
+        std::vector<DwTile> tiles;
+        for (int l = 0; l < h->NL; ++l) {
+            const LayerI& y = h->lay[l];
+            const FusedLayer& q = h->flay[l];
+            for (int m0 = 0; m0 <= y.fi; m0 += 16)
+                for (int n0 = 0; n0 < y.fo; n0 += 16) {
+                    DwTile t{};
+                    t.A = (l == 0) ? h->XT : (l == h->L + 1 ? h->ZT : h->outT[l - 1]); t.B = h->dpreT[l];
+                    t.off = y.off; t.fi = y.fi; t.fo = y.fo; t.ld = y.ld; t.l2 = y.l2; t.m0 = m0; t.n0 = n0;
+                    t.img_w = q.lds_w; t.img_b = q.lds_b; t.nn = q.nn;
+                    tiles.push_back(t);
+                }
+        }
+        if ((int)tiles.size() != h->tiles16) return fail(-4, "internal: tile table size mismatch");
+        HIPC(hipMemcpy(h->tile_tab, tiles.data(), tiles.size() * sizeof(DwTile), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -308,14 +363,48 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
     int n_kl = reparam_blocks(rows, Z);
     const bool fused_step = h->fused && mode == 0 && rows <= 512;      // two-kernel step on the transposed workspace
     if (fused_step) {
-        FusedArgs f = h->fplan;
-        for (int l = 0; l < NL; ++l) {
-            const LayerI& y = h->lay[l];
-            f.lay[l].W = Wuse + y.off; f.lay[l].bias = h->W + y.off + (long)y.fi * y.ld;
-            f.lay[l].out_g = (l < NL - 1) ? h->outT[l] : nullptr; f.lay[l].dpre_g = h->dpreT[l];
+        if (h->has_drop) {           // the image follows the post-dropout weights of this step
+            launch_build_image(s, h->Wd, h->stage_tab, h->Wimg, (int)(h->P_int / 4)); ++launches;
+        } else if (!h->img_valid) {
+            launch_build_image(s, h->W, h->stage_tab, h->Wimg, (int)(h->P_int / 4)); ++launches;
+            h->img_valid = true;
         }
-        f.X = X; f.ldx = ldx; f.rows = rows; f.eps_in = eps_in; f.Wflat = Wuse; f.stage_tab = h->stage_tab; f.Zb_g = h->ZT;
-        f.XT = h->XT; f.ldT = h->cap_rows;
+        FusedArgs f = h->fplan;
+        {
+            // stage table: forward through every layer, then backward through the activations
+            int ns = 0;
+            for (int l = 0; l < NL; ++l) {
+                const FusedLayer& q = h->flay[l];
+                FusedStage& t = f.stages[ns++];
+                t = FusedStage{};
+                t.in_off = (l == 0) ? f.lds_x : (l == L + 1 ? f.lds_z : h->flay[l - 1].lds_out);
+                t.sin = (l == 0) ? f.s_x : (l == L + 1 ? f.s_z : h->flay[l - 1].s_out);
+                t.K16 = rup16(q.fi); t.w_off = q.lds_w; t.nn = q.nn; t.N = q.fo; t.act = q.act; t.b_off = q.lds_b;
+                t.trans = 0; t.NF = rup16(q.fo);
+                if (l < NL - 1) {
+                    t.kind = (l == L) ? FK_FWD_HEADS : FK_FWD_ACT;
+                    t.out_off = q.lds_out; t.s_out = q.s_out; t.gout = h->outT[l];
+                } else {
+                    t.kind = FK_FWD_BCE; t.out_off = f.lds_d0; t.s_out = f.s_d; t.aux_off = f.lds_x; t.s_aux = f.s_x;
+                    t.gout = h->dpreT[l];
+                }
+            }
+            int cur = f.lds_d0, nxt = f.lds_d1;
+            for (int l = NL - 1; l >= 1; --l) {
+                const FusedLayer& q = h->flay[l];
+                const FusedLayer& pq = h->flay[l - 1];
+                FusedStage& t = f.stages[ns++];
+                t = FusedStage{};
+                t.in_off = cur; t.sin = f.s_d; t.K16 = rup16(q.fo); t.w_off = q.lds_w; t.nn = q.nn; t.trans = 1;
+                t.N = q.fi; t.act = pq.act; t.out_off = nxt; t.s_out = f.s_d;
+                t.aux_off = pq.lds_out; t.s_aux = pq.s_out; t.NF = rup16(pq.fo); t.gout = h->dpreT[l - 1];
+                t.kind = (l == L + 1) ? FK_BWD_LATENT : FK_BWD_ACT;
+                std::swap(cur, nxt);
+            }
+            f.n_stages = ns;
+        }
+        f.X = X; f.ldx = ldx; f.rows = rows; f.eps_in = eps_in; f.Wimg = h->Wimg; f.Zb_g = h->ZT;
+        f.XT = h->XT;
         f.seed = h->cfg.seed; f.st = h->st; f.row0_global = row0_global;
         f.lo = h->cfg.bce_lo; f.hi = h->cfg.bce_hi; f.inv_batch = inv_batch; f.bce_p = h->bce_p; f.kl_p = h->kl_p;
 #ifdef SMRT_STAMPS
@@ -330,7 +419,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             unsigned long long hb[64];
             (void)hipMemcpy(hb, dbgbuf, 64 * 8, hipMemcpyDeviceToHost);
             static int once = 0;
-            if (once++ == 3) for (int i = 1; i < 20 && hb[i]; ++i)
+            if (once++ == 3) for (int i = 1; i < 32 && hb[i]; ++i)
                 fprintf(stderr, "stamp %d: +%.2f us  (%.0f shader cycles, %.2f GHz)\n", i, (double)(hb[i] - hb[i - 1]) * 0.01,
                         (double)(hb[32 + i] - hb[32 + i - 1]), (double)(hb[32 + i] - hb[32 + i - 1]) / ((double)(hb[i] - hb[i - 1]) * 10.0));
         }
@@ -381,17 +470,10 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
     // ---- small nets, small batches: dW + optimizer in one launch, cost only when somebody reads it
     if (fused_step) {
         DwOptArgs d{};
-        int tb = 0;
-        for (int l = 0; l < NL; ++l) {
-            const LayerI& y = h->lay[l];
-            DwOptLayer& q = d.L[l];
-            q.A = (l == 0) ? h->XT : (l == L + 1 ? h->ZT : h->outT[l - 1]); q.B = h->dpreT[l]; q.off = y.off;
-            q.fi = y.fi; q.fo = y.fo; q.ld = y.ld; q.l2 = y.l2;
-            q.tiles_n = (y.fo + 15) / 16; q.tile_begin = tb;
-            tb += ((y.fi + 1 + 15) / 16) * q.tiles_n;
-        }
-        d.n_layers = NL; d.total_tiles = tb; d.rows = rows; d.ldT = h->cap_rows;
+        const int tb = h->tiles16;
+        d.tiles = h->tile_tab; d.total_tiles = tb; d.rows = rows;
         d.W = h->W; d.Wd = h->Wd; d.mask = h->mask; d.s0 = h->s0; d.s1 = h->s1; d.grad_out = o.grad_out;
+        d.Wimg = h->has_drop ? nullptr : h->Wimg;
         d.l2_partials = h->l2_p; d.st = h->st; d.ticket = h->ticket;
         d.opt = h->cfg.optimizer; d.clip = h->cfg.clip; d.has_drop = h->has_drop; d.has_l2 = h->has_l2;
         d.lr = h->cfg.learning_rate; d.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
@@ -459,6 +541,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
     p.lr = h->cfg.learning_rate; p.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
     p.gmin = h->cfg.gclip_min; p.gmax = h->cfg.gclip_max; p.keep = h->cfg.dropout_keep;
     { ProfScope ps(h, PK_OPT); launch_optimizer(s, p, nullptr); } ++launches;
+    h->img_valid = false;
     FinalizeArgs f{};
     f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p; f.n_l2 = h->n_l2;
     f.inv_batch = inv_batch; f.l2 = p.l2; f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
@@ -501,33 +584,43 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(-2, "hipStreamCreate failed"));
     h->stream = h->own_stream;
     int rc;
-    if ((rc = dalloc(&h->W, (size_t)h->P_int))) return bail(rc);
-    if ((rc = dalloc(&h->s0, (size_t)h->P_int))) return bail(rc);
-    if ((rc = dalloc(&h->s1, (size_t)h->P_int))) return bail(rc);
-    if ((rc = dalloc(&h->gtmp, (size_t)h->P_int + 4))) return bail(rc);
-    if (h->has_drop) {
-        if ((rc = dalloc(&h->Wd, (size_t)h->P_int))) return bail(rc);
-        if ((rc = dalloc(&h->mask, (size_t)h->P_int))) return bail(rc);
-    }
     h->n_l2 = optimizer_blocks(h->P_int);
-    if ((rc = dalloc(&h->l2_p, (size_t)std::max(h->n_l2, dw_opt_blocks(h->tiles16))))) return bail(rc);
-    if ((rc = dalloc(&h->ticket, 4))) return bail(rc);
+    {
+        auto layout = [&](Arena& a) {
+            a.off = 0;
+            carve(a, &h->W, (size_t)h->P_int);
+            carve(a, &h->s0, (size_t)h->P_int);
+            carve(a, &h->s1, (size_t)h->P_int);
+            carve(a, &h->Wimg, h->fused ? (size_t)h->fplan.img_total + 16 : 0);
+            carve(a, &h->st, (size_t)1);
+            carve(a, &h->ticket, (size_t)4);
+            carve(a, &h->cost_dev, (size_t)4);
+            carve(a, &h->l2_p, (size_t)std::max(h->n_l2, dw_opt_blocks(h->tiles16)));
+            carve(a, &h->stage_tab, h->fused ? (size_t)h->P_int / 4 : 0);
+            carve(a, &h->gtmp, (size_t)h->P_int + 4);
+            carve(a, &h->Wd, h->has_drop ? (size_t)h->P_int : 0);
+            carve(a, &h->mask, h->has_drop ? (size_t)h->P_int : 0);
+        };
+        Arena dry;
+        layout(dry);
+        if ((rc = arena_alloc(h->pa, dry.off))) return bail(rc);
+        layout(h->pa);
+        h->cost_cap = 2;
+    }
     if (h->fused) {
-        // where each 16-byte piece of the flat parameter buffer lands in the kernel's LDS weight images
+        // where each 16-byte piece of the flat parameter buffer lands in the image twin (float offsets)
         std::vector<int> tab((size_t)h->P_int / 4);
         for (int l = 0; l < h->NL; ++l) {
             const LayerI& y = h->lay[l];
-            const FusedLayer& q = h->fplan.lay[l];
+            const FusedLayer& q = h->flay[l];
             for (int r = 0; r <= y.fi; ++r)
                 for (int c4 = 0; c4 < y.ld; c4 += 4)
                     tab[(size_t)(y.off + (long)r * y.ld + c4) / 4] =
                         (r < y.fi) ? q.lds_w + (((r >> 2) * q.nn + c4) << 2) + (r & 3) : q.lds_b + 4 * c4;
         }
-        if ((rc = dalloc(&h->stage_tab, tab.size()))) return bail(rc);
         if (hipMemcpy(h->stage_tab, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess)
             return bail(fail(-2, "stage table upload failed"));
     }
-    if ((rc = dalloc(&h->st, 1))) return bail(rc);
     if ((rc = smrt_vae_reset_opt_state(h))) return bail(rc);
     if ((rc = ensure_train(h, cfg->max_batch))) return bail(rc);
     *out = h;
@@ -538,18 +631,10 @@ void smrt_vae_destroy(smrt_vae* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream || h->own_stream) (void)hipStreamSynchronize(h->stream);
-    float** bufs[] = {&h->W, &h->Wd, &h->mask, &h->s0, &h->s1, &h->G, &h->gtmp, &h->Zb, &h->Eb, &h->bce_p, &h->kl_p,
-                      &h->l2_p, &h->cost_dev, &h->ibuf[0], &h->ibuf[1], &h->izb};
-    for (float** b : bufs) if (*b) (void)hipFree(*b);
-    for (int l = 0; l < MAX_LAYERS; ++l) {
-        float* b4[] = {h->out[l], h->dpre[l], h->outT[l], h->dpreT[l]};
-        for (float* b : b4) if (b) (void)hipFree(b);
-    }
-    if (h->XT) (void)hipFree(h->XT);
-    if (h->ZT) (void)hipFree(h->ZT);
-    if (h->st) (void)hipFree(h->st);
-    if (h->ticket) (void)hipFree(h->ticket);
-    if (h->stage_tab) (void)hipFree(h->stage_tab);
+    if (h->pa.base) (void)hipFree(h->pa.base);
+    if (h->ta.base) (void)hipFree(h->ta.base);
+    float* ibufs[] = {h->ibuf[0], h->ibuf[1], h->izb};
+    for (float* b : ibufs) if (b) (void)hipFree(b);
     if (h->cost_pin) (void)hipHostFree(h->cost_pin);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
@@ -571,7 +656,16 @@ int smrt_vae_set_params(smrt_vae* h, const float* host_flat, int64_t n) {
     convert(h, const_cast<float*>(host_flat), in.data(), true);
     HIPC(hipStreamSynchronize(h->stream));
     HIPC(hipMemcpy(h->W, in.data(), sizeof(float) * h->P_int, hipMemcpyHostToDevice));
+    h->img_valid = false;
     return 0;
+}
+
+// Bring the LDS-image twin up to date before fused steps run (a cached epoch graph holds no rebuild node).
+static void ensure_image(smrt_vae* h) {
+    if (h->fused && !h->has_drop && !h->img_valid) {
+        launch_build_image(h->stream, h->W, h->stage_tab, h->Wimg, (int)(h->P_int / 4));
+        h->img_valid = true;
+    }
 }
 
 static int download_abi(smrt_vae* h, const float* dev, float* host_flat, int64_t n, const char* who) {
@@ -628,7 +722,6 @@ int smrt_vae_set_dropout_masks(smrt_vae* h, const float* host_flat, int64_t n) {
 // cost_dev is two floats for the handle's lifetime (slot 0: the cost that is read back, slot 1: scratch for
 // steps whose cost nobody reads) so captured graphs never hold a stale pointer; only the pinned mirror grows.
 static int ensure_cost(smrt_vae* h, long n) {
-    if (!h->cost_dev) { TRY(dalloc(&h->cost_dev, 2)); h->cost_cap = 2; }
     if (n > h->cost_pin_cap) {
         if (h->cost_pin) (void)hipHostFree(h->cost_pin);
         h->cost_pin = nullptr;
@@ -647,6 +740,7 @@ int smrt_vae_train_step(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t ro
     TRY(ensure_train(h, rows));
     TRY(ensure_cost(h, 1));
     StepOut o{h->cost_dev, grads_host ? h->gtmp : nullptr, nullptr};
+    ensure_image(h);
     TRY(enqueue_step(h, X_dev, ldx, rows, 1.0f / (float)rows, 0, eps_dev, 0, o));
     HIPC(hipGetLastError());
     HIPC(hipMemcpyAsync(h->cost_pin, h->cost_dev, sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -677,6 +771,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     }
     if (epochs_done) *epochs_done = 0;
     if (n_epochs == 0) return 0;
+    ensure_image(h);
 
     // Enqueue one epoch (every contiguous batch, ragged tail last: sklearn gen_batches, base.py:198-199).
     // The cost of the LAST batch lands in `slot` (base.py:222); other steps write a scratch slot.
@@ -806,6 +901,7 @@ static int enqueue_apply(smrt_vae* h, const float* grads_dev, float* cost_dst) {
     p.lr = h->cfg.learning_rate; p.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
     p.gmin = h->cfg.gclip_min; p.gmax = h->cfg.gclip_max; p.keep = 1.f;
     launch_optimizer(h->stream, p, nullptr);
+    h->img_valid = false;
     FinalizeArgs f{};
     f.l2p = h->l2_p; f.n_l2 = h->n_l2; f.presummed = grads_dev + h->P_int; f.l2 = p.l2;
     f.cost_out = cost_dst; f.st = h->st; f.advance = 1;

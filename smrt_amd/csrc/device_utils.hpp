@@ -8,10 +8,17 @@ namespace smrt {
 
 enum Act : int { ACT_ELU = 0, ACT_IDENTITY = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
 
+// 1 / (1 + e^-v) on the transcendental unit: v_exp_f32 + v_rcp_f32 (1 ulp each; saturates to exactly 0 / 1
+// like the IEEE expression).  The library expf + correctly rounded divide cost ~25 VALU instructions per
+// value, which dominates the epilogue of the latency-bound small-net kernels.
+__device__ __forceinline__ float fast_sigmoid(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+
 // Forward activations (reference: smrt/autoencode/autoencoder.py:28-34 -> tf.nn.*).
 __device__ __forceinline__ float act_fwd(int act, float v) {
     switch (act) {
-        case ACT_SIGMOID:  return 1.0f / (1.0f + expf(-v));
+        case ACT_SIGMOID:  return fast_sigmoid(v);
         case ACT_TANH:     return tanhf(v);
         case ACT_RELU:     return fmaxf(v, 0.0f);
         case ACT_ELU:      return v > 0.0f ? v : expm1f(v);
@@ -35,7 +42,7 @@ __device__ __forceinline__ void act_fwd4(int act, float (&v)[4]) {
     switch (act) {
         case ACT_SIGMOID:
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = 1.0f / (1.0f + expf(-v[r]));
+            for (int r = 0; r < 4; ++r) v[r] = fast_sigmoid(v[r]);
             break;
         case ACT_TANH:
 #pragma unroll

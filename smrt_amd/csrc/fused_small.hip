@@ -28,6 +28,8 @@
 namespace smrt {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 constexpr int FTM = 16;                 // rows per workgroup
 constexpr int FTHREADS = 512;          // 8 waves: two per SIMD, so one wave's epilogue/LDS latency hides under the other's MFMAs
@@ -47,294 +49,296 @@ __device__ __forceinline__ void lds_barrier() {
 //   ((kf >> 2) * nn + nf) * 4 + (kf & 3)      floats, nn = rup16(fan_out) + 1 (odd -> conflict-free strided reads)
 // Forward  (sum over kf): a lane's four k values are contiguous       -> ONE ds_read_b128.
 // Backward (sum over nf): a lane's four k values are 16 bytes apart   -> ds_read with immediate offsets.
-template <bool TRANS>
-__device__ __forceinline__ void load_frags(const float* A_lds, int sa, const float* W_lds, int nn, int c, int q, int n,
-                                           int k0, float4& a, float4& b) {
-    const int k = k0 + 4 * q;
-    a = *reinterpret_cast<const float4*>(A_lds + c * sa + k);
-    if constexpr (TRANS) {
-        const float* p = W_lds + (((n >> 2) * nn + k) << 2) + (n & 3);    // Wop[k][n] = W[kf = n][nf = k]
-        b = make_float4(p[0], p[4], p[8], p[12]);
-    } else {
-        b = *reinterpret_cast<const float4*>(W_lds + ((((k0 >> 2) + q) * nn + n) << 2));   // Wop[k][n] = W[kf = k][nf = n]
-    }
-}
-
-// C[16 x N] = A_lds[16 x K16] . Wop, all operands in LDS, zero padded to multiples of 16.
-// epi(row0, col, v[4]) is called once per lane for col < N with the values of rows row0 .. row0+3.
-template <bool TRANS, class Epi>
-__device__ __forceinline__ void tile_gemm16(const float* A_lds, int sa, int K16, const float* W_lds, int nn,
-                                            int N, Epi&& epi) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, q = lane >> 4;
-    for (int n0 = wave * 16; n0 < N; n0 += 16 * FWAVES) {
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-        const int n = n0 + c;
-        int k0 = 0;
-        for (; k0 + 64 <= K16; k0 += 64) {
-            float4 a0, a1, a2, a3, b0, b1, b2, b3;
-            load_frags<TRANS>(A_lds, sa, W_lds, nn, c, q, n, k0, a0, b0);
-            load_frags<TRANS>(A_lds, sa, W_lds, nn, c, q, n, k0 + 16, a1, b1);
-            load_frags<TRANS>(A_lds, sa, W_lds, nn, c, q, n, k0 + 32, a2, b2);
-            load_frags<TRANS>(A_lds, sa, W_lds, nn, c, q, n, k0 + 48, a3, b3);
-            MFMA16(a0.x, b0.x, acc0); MFMA16(a1.x, b1.x, acc1); MFMA16(a2.x, b2.x, acc2); MFMA16(a3.x, b3.x, acc3);
-            MFMA16(a0.y, b0.y, acc0); MFMA16(a1.y, b1.y, acc1); MFMA16(a2.y, b2.y, acc2); MFMA16(a3.y, b3.y, acc3);
-            MFMA16(a0.z, b0.z, acc0); MFMA16(a1.z, b1.z, acc1); MFMA16(a2.z, b2.z, acc2); MFMA16(a3.z, b3.z, acc3);
-            MFMA16(a0.w, b0.w, acc0); MFMA16(a1.w, b1.w, acc1); MFMA16(a2.w, b2.w, acc2); MFMA16(a3.w, b3.w, acc3);
-        }
-        for (; k0 < K16; k0 += 16) {
-            float4 a0, b0;
-            load_frags<TRANS>(A_lds, sa, W_lds, nn, c, q, n, k0, a0, b0);
-            MFMA16(a0.x, b0.x, acc0); MFMA16(a0.y, b0.y, acc1); MFMA16(a0.z, b0.z, acc2); MFMA16(a0.w, b0.w, acc3);
-        }
-        if (n < N) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
-            epi(4 * q, n, v);                       // rows 4q .. 4q+3 of column n
-        }
-    }
-}
+//
+// Global activations / gradients for the weight-gradient kernel are "blocked transposed": [row block of 16][feature][16
+// rows].  A lane's four rows of one column are one 16-byte store, a wave's store covers 1 KiB contiguous, and the
+// weight-gradient kernel's MFMA fragments are 1 KiB contiguous loads of the same buffer.
 
 #ifdef SMRT_STAMPS
 #define STAMP() do { __syncthreads(); if (a.dbg && blockIdx.x == 0 && tid == 0) { a.dbg[stamp_i] = wall_clock64(); a.dbg[32 + stamp_i] = clock64(); } ++stamp_i; } while (0)
-#define STAMP_NS() do { if (a.dbg && blockIdx.x == 0 && tid == 0) { a.dbg[stamp_i] = wall_clock64(); a.dbg[32 + stamp_i] = clock64(); } ++stamp_i; } while (0)
+#define STAMP_NS() do { if (a.dbg && blockIdx.x == 0 && tid == 0 && stamp_i < 31) { a.dbg[stamp_i] = wall_clock64(); a.dbg[32 + stamp_i] = clock64(); } ++stamp_i; } while (0)
 #else
 #define STAMP() do { } while (0)
 #define STAMP_NS() do { } while (0)
 #endif
 
-constexpr int STAGE_U = 12;             // 16-byte weight loads in flight per lane (one batch = 96 KB per workgroup)
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
 
 __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs a) {
     extern __shared__ __align__(16) float lds[];
-    __shared__ float red[FWAVES];
-    const int tid = threadIdx.x;
+    __shared__ float red[FWAVES], red2[FWAVES];
+    __shared__ int4 sdesc[2 * MAX_LAYERS * 5 + 5];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = UNI(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
     const int r0 = blockIdx.x * FTM;
     const int rows_here = min(FTM, a.rows - r0);
-    const int L = a.L, NL = a.NL, Z = a.Z;
+    const int Z = a.Z;
 #ifdef SMRT_STAMPS
     int stamp_i = 0;
 #endif
     STAMP();
 
-    // ---- issue every global load this kernel depends on, in one batch: weights, X tile, step counter, epsilon,
-    // and the per-layer descriptors (kernel arguments live in memory: the first scalar load of each cache
-    // line is a full memory round trip, so touch them all now instead of one per stage)
-    __shared__ FusedLayer slay[MAX_LAYERS];
+    // ---- issue every global load this kernel depends on, in one batch.  The weights arrive by LDS-DMA: the
+    // parameter buffer has a twin laid out exactly like this kernel's LDS weight image (k-quad interleaved, zero
+    // padded; kept current by the optimizer epilogue), so staging is a straight 16-byte-per-lane copy with no
+    // VGPRs and no ds_write pass.  Kernel arguments live in memory too (the first scalar load of each cache
+    // line is a full round trip): the stage descriptors are fetched now, not one per stage.
+    const uint32_t step = a.st->step;                      // scalar load: not queued behind the vector loads below
     {
-        constexpr int NW = (int)(sizeof(FusedLayer) * MAX_LAYERS / sizeof(int));
-        const int* src = reinterpret_cast<const int*>(&a.lay[0]);
-        int* dstl = reinterpret_cast<int*>(&slay[0]);
-        for (int i = tid; i < NW; i += FTHREADS) dstl[i] = src[i];
+        const int n4 = a.img_total >> 2;                   // multiple of 64: every wave-instruction is full
+        for (int i = tid; i < n4; i += FTHREADS)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(a.Wimg + 4L * i), (lds_ptr_t)(lds + 4 * (i - lane)), 16, 0, 0);
     }
-    const uint32_t step = a.st->step;
+    {
+        const int nw = a.n_stages * 5;
+        const int4* src = reinterpret_cast<const int4*>(&a.stages[0]);
+        if (tid < nw) sdesc[tid] = src[tid];
+    }
     float* xs = lds + a.lds_x;
     const int xf4_per_row = (a.D + 3) >> 2;
     float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool x_small = FTM * xf4_per_row <= FTHREADS;         // one float4 per lane covers the tile
-    if (x_small && tid < rows_here * xf4_per_row && ((a.D & 3) == 0)) {
+    const bool x_fast = (FTM * xf4_per_row <= FTHREADS) && ((a.D & 3) == 0);   // one float4 per lane covers the tile
+    if (x_fast && tid < rows_here * xf4_per_row) {
         const int r = tid / xf4_per_row, c4 = (tid - r * xf4_per_row) << 2;
         xv = *reinterpret_cast<const float4*>(a.X + (long)(r0 + r) * a.ldx + c4);
     }
+    // epsilon of the reparameterisation depends on (seed, step, row) only: injected values are fetched, Philox
+    // values are computed, while the weight image is still in flight
     float eps_pre[2] = {0.f, 0.f};
-    if (a.eps_in) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = tid + u * FTHREADS;
-            if (i < rows_here * Z) eps_pre[u] = a.eps_in[(long)r0 * Z + i];
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * FTHREADS;
+        if (i < rows_here * Z) {
+            if (a.eps_in) eps_pre[u] = a.eps_in[(long)r0 * Z + i];
+            else          eps_pre[u] = philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + r0) * Z + i);
         }
     }
-    const int total_f4 = a.w_total >> 2;
-    for (int base = 0; base < total_f4; base += FTHREADS * STAGE_U) {
-        f32x4 v[STAGE_U];                                  // native vectors: an array of HIP float4 structs lands in scratch
-        int dst[STAGE_U];
-#pragma unroll
-        for (int u = 0; u < STAGE_U; ++u) {
-            // clamped + unconditional: a branch around a load makes hipcc wait for each one separately;
-            // a clamped duplicate later rewrites the last element with the same value.
-            const int i = min(base + tid + u * FTHREADS, total_f4 - 1);
-            v[u] = *reinterpret_cast<const f32x4*>(a.Wflat + 4L * i);
-            dst[u] = a.stage_tab[i];                       // LDS float offset of this 16-byte piece (host-built)
-        }
-        if (base == 0) {
-            // zero the LDS (pads must read as 0) while the loads are in flight
-            float4* l4 = reinterpret_cast<float4*>(lds);
-            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int i = tid; i < a.lds_total / 4; i += FTHREADS) l4[i] = z4;
-            lds_barrier();
-        }
-#pragma unroll
-        for (int u = 0; u < STAGE_U; ++u) {
-            float* d = lds + dst[u];                       // consecutive fan-out columns are 4 floats apart in the image
-            d[0] = v[u][0]; d[4] = v[u][1]; d[8] = v[u][2]; d[12] = v[u][3];
-        }
+    {
+        // zero the activation part of the LDS (pads must read as 0) while the loads are in flight
+        float4* l4 = reinterpret_cast<float4*>(lds);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = (a.img_total >> 2) + tid; i < a.lds_total / 4; i += FTHREADS) l4[i] = z4;
+        lds_barrier();
     }
-    // X tile into LDS, and its transposed copy XT[col][ldT] for the weight-gradient kernel (zeros on padded rows)
-    if (x_small && ((a.D & 3) == 0)) {
+    // X tile into LDS (zeros on padded rows)
+    if (x_fast) {
         if (tid < FTM * xf4_per_row) {
             const int r = tid / xf4_per_row, c4 = (tid - r * xf4_per_row) << 2;
             *reinterpret_cast<float4*>(xs + r * a.s_x + c4) = xv;
-            float* xt = a.XT + (long)c4 * a.ldT + r0 + r;
-            xt[0] = xv.x; xt[a.ldT] = xv.y; xt[2 * a.ldT] = xv.z; xt[3 * a.ldT] = xv.w;
         }
     } else {
         for (int i = tid; i < FTM * a.D; i += FTHREADS) {
             const int r = i / a.D, cc = i - r * a.D;
-            const float xval = (r < rows_here) ? a.X[(long)(r0 + r) * a.ldx + cc] : 0.0f;
-            xs[r * a.s_x + cc] = xval;
-            a.XT[(long)cc * a.ldT + r0 + r] = xval;
+            xs[r * a.s_x + cc] = (r < rows_here) ? a.X[(long)(r0 + r) * a.ldx + cc] : 0.0f;
         }
     }
-    lds_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // every load above has landed (LDS-DMA included)
+    __builtin_amdgcn_s_barrier();
+    // blocked transposed copy of the X tile for the weight-gradient kernel: stores issued after the wait, so
+    // nothing on the critical path waits for them
+    {
+        float* xt = a.XT + (long)blockIdx.x * ((a.D + 15) & ~15) * 16;
+        for (int i = tid; i < FTM * a.D; i += FTHREADS) {
+            const int cc = i >> 4, r = i & 15;
+            xt[i] = xs[r * a.s_x + cc];                     // i == cc * 16 + r: fully coalesced
+        }
+    }
     STAMP();
 
     float* zs = lds + a.lds_z;
     float* es = lds + a.lds_e;
-    float* dcur = lds + a.lds_d0;
-    float* dnext = lds + a.lds_d1;
     float bce = 0.f, kl = 0.f;
-
-    // Descriptor fields are copied into locals at the top of each stage: read through `slay[l]` inside the
-    // epilogue they are re-fetched from the kernel-argument segment for every element.
     const float lo = a.lo, hi = a.hi, inv_batch = a.inv_batch;
-    const int s_x = a.s_x, s_z = a.s_z, s_d = a.s_d;
-    const long ldT = a.ldT;
+    const int s_z = a.s_z;
 
-    // Epilogues are branch-free over the lane's four rows: workspace rows are padded to a multiple of 16 so
-    // rows past the batch are computed and stored like the others (their dPre is forced to 0, nothing reads them).
-    // ---- forward
-    for (int l = 0; l < NL; ++l) {
-        const float* in = (l == 0) ? xs : (l == L + 1 ? zs : lds + slay[l - 1].lds_out);
-        const int sin = (l == 0) ? s_x : (l == L + 1 ? s_z : slay[l - 1].s_out);
-        const float* wimg = lds + slay[l].lds_w;
-        const float* bias = lds + slay[l].lds_b;                       // stride 4 (same interleave as the weights)
-        const int fi = slay[l].fi, fo = slay[l].fo, nn = slay[l].nn, act = slay[l].act;
-        const int K16 = (fi + 15) & ~15;
-        if (l < NL - 1) {
-            float* o = lds + slay[l].lds_out;
-            const int s_out = slay[l].s_out;
-            float* og = slay[l].out_g + r0;                                   // transposed: [col][ldT], rows contiguous
-            tile_gemm16<false>(in, sin, K16, wimg, nn, fo, [&](int row0, int col, float (&v)[4]) {
-                const float bcol = bias[4 * col];
+    // ---- every GEMM stage (forward layers, then backward through the activations) runs through this one body
+    int4 d0 = sdesc[0], d1 = sdesc[1], d2 = sdesc[2], d3 = sdesc[3], d4 = sdesc[4];
+#pragma unroll 1
+    for (int st = 0; st < a.n_stages; ++st) {
+        const int in_off = UNI(d0.x), sin = UNI(d0.y), K16 = UNI(d0.z), w_off = UNI(d0.w);
+        const int nn = UNI(d1.x), N = UNI(d1.y), kind = UNI(d1.z), act = UNI(d1.w);
+        const int out_off = UNI(d2.x), s_out = UNI(d2.y), b_off = UNI(d2.z), aux_off = UNI(d2.w);
+        const int s_aux = UNI(d3.x), NF = UNI(d3.y), trans = UNI(d3.z);
+        float* gblk = reinterpret_cast<float*>(((unsigned long long)(unsigned)UNI(d4.y) << 32) | (unsigned)UNI(d4.x))
+                      + (long)blockIdx.x * NF * 16;
+        const int N16 = (N + 15) & ~15;
+        const float* ap = lds + in_off + c * sin + 4 * q;
+        // the next stage's record is fetched now (the table has room for a read past the last stage)
+        const int4 e0 = sdesc[5 * st + 5], e1 = sdesc[5 * st + 6], e2 = sdesc[5 * st + 7], e3 = sdesc[5 * st + 8],
+                   e4 = sdesc[5 * st + 9];
+
+#pragma unroll 1
+        for (int n0 = wave * 16; n0 < N16; n0 += 16 * FWAVES) {
+            const int n = n0 + c;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+            // 64-wide k batches (4 k-blocks, 16 MFMAs into 4 independent chains).  The fragments of batch i+1 are
+            // requested BEFORE the MFMAs of batch i (the empty asm pins the order: left alone, hipcc sinks every LDS
+            // read to its first use and each k-block then pays the full LDS latency); look-ahead addresses are
+            // clamped (a harmless re-read), k-blocks past K16 are skipped by a uniform branch.
+            const int klast = K16 - 16;
+            f32x4 av[4], bv[4], an[4], bn[4];
+            const float* bpn = lds + w_off + ((q * nn + n) << 2);                               // forward image walk
+            const float* bpt = lds + w_off + ((((n >> 2) * nn) + 4 * q) << 2) + (n & 3);        // backward image walk
+            auto fetch = [&](int kb, f32x4 (&fa)[4], f32x4 (&fb)[4]) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += bcol;
-                act_fwd4(act, v);                                                     // layer.py:368
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[(row0 + r) * s_out + col] = v[r];
-                *reinterpret_cast<float4*>(og + (long)col * ldT + row0) = make_float4(v[0], v[1], v[2], v[3]);
-            });
-            STAMP_NS();
-            lds_barrier();
-            STAMP_NS();
-            if (l == L) {
-                // z = mu + eps * exp(log_sigma)  (layer.py:279) and the KL row terms (_ae_utils.py:49)
-                float* zg = a.Zb_g + r0;                                      // transposed [Z][ldT]
-                for (int i = tid, u = 0; i < FTM * Z; i += FTHREADS, ++u) {
-                    const int r = i / Z, k = i - r * Z;
-                    if (r >= rows_here) zg[(long)k * ldT + r] = 0.0f;          // finite filler for the padded rows
-                    if (r < rows_here) {
-                        const float mu = o[r * s_out + k], ls = o[r * s_out + Z + k];
-                        float e;
-                        if (a.eps_in) e = (u == 0) ? eps_pre[0] : (u == 1 ? eps_pre[1] : a.eps_in[(long)r0 * Z + i]);
-                        else e = philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + r0 + r) * Z + k);
-                        const float z = mu + e * expf(ls);
-                        zs[r * s_z + k] = z;
-                        es[r * s_z + k] = e;
-                        zg[(long)k * ldT + r] = z;
-                        kl += -0.5f * (1.0f + 2.0f * ls - mu * mu - expf(2.0f * ls));
+                for (int j = 0; j < 4; ++j) {
+                    const int k = min(kb + 16 * j, klast);
+                    fa[j] = *reinterpret_cast<const f32x4*>(ap + k);
+                    if (!trans) {
+                        fb[j] = *reinterpret_cast<const f32x4*>(bpn + k * nn);      // Wop[k][n] = W[kf = k][nf = n]
+                    } else {
+                        const float* p = bpt + (k << 2);                           // Wop[k][n] = W[kf = n][nf = k]
+                        fb[j][0] = p[0]; fb[j][1] = p[4]; fb[j][2] = p[8]; fb[j][3] = p[12];
                     }
                 }
-                lds_barrier();
+            };
+            fetch(0, av, bv);
+#pragma unroll 1
+            for (int k0 = 0; k0 < K16; k0 += 64) {
+                const bool more = (k0 + 64) < K16;
+                if (more) fetch(k0 + 64, an, bn);
+                asm volatile("" ::: "memory");
+                const int nblk = min(4, (K16 - k0) >> 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j < nblk) {
+                        MFMA16(av[j][0], bv[j][0], acc0); MFMA16(av[j][1], bv[j][1], acc1);
+                        MFMA16(av[j][2], bv[j][2], acc2); MFMA16(av[j][3], bv[j][3], acc3);
+                    }
+                }
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { av[j] = an[j]; bv[j] = bn[j]; }
+                }
             }
-        } else {
-            // sigmoid output + clipped Bernoulli NLL + dL/dpre in one epilogue (layer.py:333-338, _ae_utils.py:31-32)
-            float* dg = slay[l].dpre_g + r0;
-            tile_gemm16<false>(in, sin, K16, wimg, nn, fo, [&](int row0, int col, float (&v)[4]) {
-                const float bcol = bias[4 * col];
-                float dv[4];
+            float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool valid = (row0 + r) < rows_here;
-                    const float p = 1.0f / (1.0f + expf(-(v[r] + bcol)));
-                    const float x = xs[(row0 + r) * s_x + col];
-                    const float pl = fmaxf(p, lo), pc = fminf(pl, hi), om = 1.0f - pc;
-                    const float term = x * logf(pc) + (1.0f - x) * logf(om);
-                    bce -= valid ? term : 0.0f;
-                    const bool pass = valid && (p >= lo) && (pl <= hi);
-                    const float dp = pass ? -(x / pc - (1.0f - x) / om) * inv_batch : 0.0f;
-                    const float d = valid ? dp * p * (1.0f - p) : 0.0f;
-                    dv[r] = d;
-                    dcur[(row0 + r) * s_d + col] = d;
-                }
-                *reinterpret_cast<float4*>(dg + (long)col * ldT + row0) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-            });
-            lds_barrier();
-        }
-    }
-    STAMP();
-
-    // ---- backward through the activations: dcur holds dPre of layer l, [16 x fo_l] zero padded
-    for (int l = NL - 1; l >= 1; --l) {
-        const float* wimg = lds + slay[l].lds_w;
-        const int fi = slay[l].fi, nn = slay[l].nn;
-        const int K16 = (slay[l].fo + 15) & ~15;
-        const float* po = lds + slay[l - 1].lds_out;
-        const int p_sout = slay[l - 1].s_out, p_act = slay[l - 1].act;
-        float* pg = slay[l - 1].dpre_g + r0;
-        if (l == L + 1) {
-            // l - 1 == L: the fused heads.  v = dL/dz through the reparameterisation and the KL term.
-            tile_gemm16<true>(dcur, s_d, K16, wimg, nn, fi, [&](int row0, int col, float (&v)[4]) {
-                float mu[4], ls[4], g_mu[4], g_ls[4];
+            for (int r = 0; r < 4; ++r) v[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+            // rows 4q .. 4q+3 of column n.  Workspace rows are padded to a multiple of 16, so rows past the batch are
+            // computed and stored like the others (their dPre is forced to 0, nothing reads them).
+            float* o = lds + out_off + (4 * q) * s_out + n;
+            float* g = gblk + n * 16 + 4 * q;
+            if (kind <= FK_FWD_HEADS) {
+                // y = act(x.W + b)                                                     layer.py:368
+                if (n < N) {
+                    const float bcol = lds[b_off + 4 * n];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    mu[r] = po[(row0 + r) * p_sout + col];
-                    ls[r] = po[(row0 + r) * p_sout + Z + col];
-                    const float e = es[(row0 + r) * s_z + col];
-                    g_mu[r] = v[r] + mu[r] * inv_batch;
-                    g_ls[r] = v[r] * e * expf(ls[r]) + (expf(2.0f * ls[r]) - 1.0f) * inv_batch;
-                }
-                act_bwd4(p_act, mu, g_mu);
-                act_bwd4(p_act, ls, g_ls);
+                    for (int r = 0; r < 4; ++r) v[r] += bcol;
+                    act_fwd4(act, v);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool valid = (row0 + r) < rows_here;
-                    g_mu[r] = valid ? g_mu[r] : 0.0f;
-                    g_ls[r] = valid ? g_ls[r] : 0.0f;
-                    dnext[(row0 + r) * s_d + col] = g_mu[r];
-                    dnext[(row0 + r) * s_d + Z + col] = g_ls[r];
+                    for (int r = 0; r < 4; ++r) o[r * s_out] = v[r];
+                    *reinterpret_cast<float4*>(g) = make_float4(v[0], v[1], v[2], v[3]);
                 }
-                *reinterpret_cast<float4*>(pg + (long)col * ldT + row0) = make_float4(g_mu[0], g_mu[1], g_mu[2], g_mu[3]);
-                *reinterpret_cast<float4*>(pg + (long)(Z + col) * ldT + row0) = make_float4(g_ls[0], g_ls[1], g_ls[2], g_ls[3]);
-            });
-        } else {
-            tile_gemm16<true>(dcur, s_d, K16, wimg, nn, fi, [&](int row0, int col, float (&v)[4]) {
+            } else if (kind == FK_FWD_BCE) {
+                // sigmoid output + clipped Bernoulli NLL + dL/dpre (layer.py:333-338, _ae_utils.py:31-32)
+                if (n < N) {
+                    const float bcol = lds[b_off + 4 * n];
+                    const float* xr = lds + aux_off + (4 * q) * s_aux + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool valid = (4 * q + r) < rows_here;
+                        const float p = fast_sigmoid(v[r] + bcol);
+                        const float x = xr[r * s_aux];
+                        const float pl = fmaxf(p, lo), pc = fminf(pl, hi), om = 1.0f - pc;
+                        const float term = x * __logf(pc) + (1.0f - x) * __logf(om);
+                        bce -= valid ? term : 0.0f;
+                        // TF clip_by_value gradient gate: Maximum passes where p >= lo, Minimum where max(p,lo) <= hi
+                        const bool pass = valid && (p >= lo) && (pl <= hi);
+                        const float dp = pass ? -(x * __builtin_amdgcn_rcpf(pc) - (1.0f - x) * __builtin_amdgcn_rcpf(om)) * inv_batch : 0.0f;
+                        v[r] = valid ? dp * p * (1.0f - p) : 0.0f;
+                        o[r * s_out] = v[r];
+                    }
+                    *reinterpret_cast<float4*>(g) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else if (kind == FK_BWD_ACT) {
+                // dPre_prev = (dPre . W^T) * act'(y_prev); pad columns come out as exact zeros (zero weights, zero y)
+                const float* po = lds + aux_off + (4 * q) * s_aux + n;
                 float yv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) yv[r] = po[(row0 + r) * p_sout + col];
-                act_bwd4(p_act, yv, v);
+                for (int r = 0; r < 4; ++r) yv[r] = po[r * s_aux];
+                act_bwd4(act, yv, v);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dnext[(row0 + r) * s_d + col] = v[r];
-                *reinterpret_cast<float4*>(pg + (long)col * ldT + row0) = make_float4(v[0], v[1], v[2], v[3]);
-            });
-        }
-        // the next stage reads k up to rup16(width just written): clear the tail this stage did not write
-        {
-            const int wrote = (l == L + 1) ? 2 * Z : fi;
-            const int tail = ((wrote + 15) & ~15) - wrote;
-            for (int i = tid; i < FTM * tail; i += FTHREADS) {
-                const int r = i / tail;
-                dnext[r * s_d + wrote + (i - r * tail)] = 0.f;
+                for (int r = 0; r < 4; ++r) o[r * s_out] = v[r];
+                *reinterpret_cast<float4*>(g) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                // FK_BWD_LATENT: v = dL/dz through the reparameterisation and the KL term into both heads
+                //   dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B     layer.py:279, _ae_utils.py:49
+                if (n < N) {
+                    const float* po = lds + aux_off + (4 * q) * s_aux + n;
+                    const float* er = es + (4 * q) * s_z + n;
+                    float mu[4], ls[4], g_mu[4], g_ls[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        mu[r] = po[r * s_aux];
+                        ls[r] = po[r * s_aux + Z];
+                        const float e = er[r * s_z];
+                        const float el = __expf(ls[r]);
+                        g_mu[r] = v[r] + mu[r] * inv_batch;
+                        g_ls[r] = v[r] * e * el + (el * el - 1.0f) * inv_batch;
+                    }
+                    act_bwd4(act, mu, g_mu);
+                    act_bwd4(act, ls, g_ls);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool valid = (4 * q + r) < rows_here;
+                        g_mu[r] = valid ? g_mu[r] : 0.0f;
+                        g_ls[r] = valid ? g_ls[r] : 0.0f;
+                        o[r * s_out] = g_mu[r];
+                        o[r * s_out + Z] = g_ls[r];
+                    }
+                    *reinterpret_cast<float4*>(g) = make_float4(g_mu[0], g_mu[1], g_mu[2], g_mu[3]);
+                    *reinterpret_cast<float4*>(g + Z * 16) = make_float4(g_ls[0], g_ls[1], g_ls[2], g_ls[3]);
+                }
             }
         }
+        if (kind == FK_BWD_LATENT) {
+            // the next stage reads k up to rup16(2Z): clear the tail this stage did not write
+            const int wrote = 2 * Z, tail = ((wrote + 15) & ~15) - wrote;
+            for (int i = tid; i < FTM * tail; i += FTHREADS) {
+                const int r = i / tail;
+                lds[out_off + r * s_out + wrote + (i - r * tail)] = 0.f;
+            }
+        }
+        STAMP_NS();
         lds_barrier();
-        float* t = dcur; dcur = dnext; dnext = t;
+        if (kind == FK_FWD_HEADS) {
+            // z = mu + eps * exp(log_sigma)  (layer.py:279) and the KL row terms (_ae_utils.py:49)
+            const float* o = lds + out_off;
+            float* zg = a.Zb_g + (long)blockIdx.x * ((Z + 15) & ~15) * 16;    // blocked transposed [rup16(Z)][16]
+            for (int i = tid, u = 0; i < FTM * Z; i += FTHREADS, ++u) {
+                const int r = i / Z, k = i - r * Z;
+                float z = 0.0f;                                              // finite filler for the padded rows
+                if (r < rows_here) {
+                    const float mu = o[r * s_out + k], ls = o[r * s_out + Z + k];
+                    float e;
+                    if (u < 2) e = (u == 0) ? eps_pre[0] : eps_pre[1];
+                    else if (a.eps_in) e = a.eps_in[(long)r0 * Z + i];
+                    else e = philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + r0) * Z + i);
+                    const float el = __expf(ls);
+                    z = mu + e * el;
+                    zs[r * s_z + k] = z;
+                    es[r * s_z + k] = e;
+                    kl += -0.5f * (1.0f + 2.0f * ls - mu * mu - el * el);
+                }
+                zg[k * 16 + r] = z;
+            }
+            lds_barrier();
+        }
+        d0 = e0; d1 = e1; d2 = e2; d3 = e3; d4 = e4;
     }
     STAMP();
 
-    const float bsum = block_sum<FWAVES>(bce, red);
-    const float ksum = block_sum<FWAVES>(kl, red);
-    if (tid == 0) { a.bce_p[blockIdx.x] = bsum; a.kl_p[blockIdx.x] = ksum; }
+    // both partial sums in one pass: wave shuffles, one LDS exchange, fixed summation order
+    bce = wave_sum(bce); kl = wave_sum(kl);
+    if (lane == 0) { red[wave] = bce; red2[wave] = kl; }
+    __syncthreads();
+    if (tid == 0) {
+        float bsum = 0.f, ksum = 0.f;
+#pragma unroll
+        for (int i = 0; i < FWAVES; ++i) { bsum += red[i]; ksum += red2[i]; }
+        a.bce_p[blockIdx.x] = bsum; a.kl_p[blockIdx.x] = ksum;
+    }
     STAMP();
 }
 
@@ -354,9 +358,9 @@ int fused_set_max_lds(int bytes) {
 // =====================================================================================
 __device__ __forceinline__ float opt_apply(int opt, float lr, float alpha, float w, float g, float& s0, float& s1) {
     switch (opt) {
-        case 1:     // RMSProp: decay .9, momentum 0, eps 1e-10 (rms slot starts at 1)
+        case 1:     // RMSProp: decay .9, momentum 0, eps 1e-10 (rms slot starts at 1); v_rsq_f32 is 1 ulp
             s0 = s0 + (g * g - s0) * (1.0f - 0.9f);
-            s1 = s1 * 0.0f + lr * g / sqrtf(s0 + 1e-10f);
+            s1 = s1 * 0.0f + lr * g * __builtin_amdgcn_rsqf(s0 + 1e-10f);
             return w - s1;
         case 2:     // Adam
             s0 = s0 + (g - s0) * (1.0f - 0.9f);
@@ -378,7 +382,8 @@ __device__ __forceinline__ float opt_apply(int opt, float lr, float alpha, float
 
 __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs a) {
     __shared__ float red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, q = lane >> 4;
 #ifdef SMRT_STAMPS
 #define BST(i) do { if (a.dbg && blockIdx.x == 0 && tid == 0) a.dbg[i] = wall_clock64(); } while (0)
@@ -388,15 +393,11 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
     BST(20);
     const int t = blockIdx.x * 4 + wave;
     const bool live = t < a.total_tiles;
-    const int tt = live ? t : a.total_tiles - 1;           // idle waves shadow the last tile and store nothing
-
-    int li = 0;
-#pragma unroll 1
-    for (int i = 1; i < a.n_layers; ++i) if (tt >= a.L[i].tile_begin) li = i;
-    const DwOptLayer& Ly = a.L[li];
-    const int lt = tt - Ly.tile_begin;
-    const int m0 = (lt / Ly.tiles_n) * 16, n0 = (lt % Ly.tiles_n) * 16;
-    const int fi = Ly.fi, fo = Ly.fo, rows = a.rows;
+    // ONE 64-byte scalar load from a device-resident table describes this wave's tile (idle waves shadow the
+    // last tile and store nothing).  Walking the per-layer kernel arguments instead costs a dependent memory
+    // round trip per layer.
+    const DwTile T = a.tiles[live ? t : a.total_tiles - 1];
+    const int m0 = T.m0, n0 = T.n0, fi = T.fi, fo = T.fo, rows = a.rows;
 
     // ---- batch 1 of loads: the optimizer operands of this lane's four output elements
     const bool has_s0 = a.opt != 0 && a.opt != 5;
@@ -408,24 +409,25 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
     for (int r = 0; r < 4; ++r) {
         const int row = m0 + 4 * q + r;
         ok[r] = live && row <= fi && col < fo;               // row == fi is the bias
-        idx[r] = Ly.off + (long)min(row, fi) * Ly.ld + min(col, fo - 1);
+        idx[r] = T.off + (long)min(row, fi) * T.ld + min(col, fo - 1);
         w[r] = a.W[idx[r]];
         s0[r] = has_s0 ? a.s0[idx[r]] : 0.f;
         s1[r] = has_s1 ? a.s1[idx[r]] : 0.f;
         wd[r] = a.has_drop ? a.Wd[idx[r]] : w[r];
         mk[r] = a.has_drop ? a.mask[idx[r]] : 1.f;
     }
-    float alpha = 0.f;
-    if (a.opt == 2) alpha = a.lr * sqrtf(1.0f - a.st->b2pow) / (1.0f - a.st->b1pow);
+    const float b1pow = a.st->b1pow, b2pow = a.st->b2pow;     // used in the epilogue only (Adam)
 
     BST(21);
-    // ---- [X | 1]^T . dPre over all rows.  Both operands are stored TRANSPOSED ([feature][row], rows contiguous)
-    // by the forward/backward kernel, so a lane's four k values are one 16-byte load; rows past the batch hold
-    // dPre = 0 (and finite activations), so no k masking is needed up to rup16(rows).
+    // ---- [X | 1]^T . dPre over all rows.  Both operands are stored blocked transposed ([row block][feature][16 rows])
+    // by the forward/backward kernel: a lane's four k values are one 16-byte load and a wave's load is 1 KiB
+    // contiguous; rows past the batch hold dPre = 0 (and finite activations), so no k masking is needed up to
+    // rup16(rows).
     const int m = m0 + c, mm = min(m, fi - 1);                // A operand: output row m (input feature); m == fi -> ones
     const int n = n0 + c, nn = min(n, fo - 1);                // B operand: output col n
-    const float* Ap = Ly.A + (long)mm * a.ldT + 4 * q;
-    const float* Bp = Ly.B + (long)nn * a.ldT + 4 * q;
+    const int NFA = (fi + 15) & ~15, NFB = (fo + 15) & ~15;   // feature counts of the blocked buffers
+    const float* Ap = T.A + mm * 16 + 4 * q;                  // row block j of feature f: ((j * NF + f) * 16) floats
+    const float* Bp = T.B + nn * 16 + 4 * q;
     const bool ones = (m == fi);
     const int rows16 = (rows + 15) & ~15;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
@@ -433,9 +435,9 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
         f32x4 av[8], bv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = min(k0 + 16 * j, rows16 - 16);      // clamped + unconditional
-            av[j] = *reinterpret_cast<const f32x4*>(Ap + k);
-            bv[j] = *reinterpret_cast<const f32x4*>(Bp + k);
+            const long jb = min(k0 + 16 * j, rows16 - 16);    // clamped + unconditional; == 16 * row block
+            av[j] = *reinterpret_cast<const f32x4*>(Ap + jb * NFA);
+            bv[j] = *reinterpret_cast<const f32x4*>(Bp + jb * NFB);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -457,22 +459,42 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
 
     BST(22);
     // ---- epilogue: L2, dropout backward, value clip, optimizer (base.py:127-149)
+    float alpha = 0.f;
+    if (a.opt == 2) alpha = a.lr * sqrtf(1.0f - b2pow) / (1.0f - b1pow);
     float l2acc = 0.f;
+    float wn[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float g = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
         const bool is_w = (m0 + 4 * q + r) < fi;
+        wn[r] = w[r];
         if (ok[r]) {
             if (is_w) {
-                if (a.has_l2 && Ly.l2) { g += a.l2 * wd[r]; l2acc += 0.5f * wd[r] * wd[r]; }
+                if (a.has_l2 && T.l2) { g += a.l2 * wd[r]; l2acc += 0.5f * wd[r] * wd[r]; }
                 if (a.has_drop) g = (g / a.keep) * mk[r];
             }
             if (a.grad_out) a.grad_out[idx[r]] = g;
             if (a.clip) g = fminf(fmaxf(g, a.gmin), a.gmax);
-            const float wn = opt_apply(a.opt, a.lr, alpha, w[r], g, s0[r], s1[r]);
-            a.W[idx[r]] = wn;
+            wn[r] = opt_apply(a.opt, a.lr, alpha, w[r], g, s0[r], s1[r]);
+            a.W[idx[r]] = wn[r];
             if (has_s0) a.s0[idx[r]] = s0[r];
             if (has_s1) a.s1[idx[r]] = s1[r];
+        }
+    }
+    // the LDS-image twin read by the next step's forward/backward kernel: this lane's four fan-in rows of one
+    // column are one k-quad of the interleaved image, i.e. one 16-byte store
+    if (a.Wimg && live && col < fo) {
+        const int row0 = m0 + 4 * q;
+        if (row0 + 3 < fi) {
+            *reinterpret_cast<float4*>(a.Wimg + T.img_w + ((((row0 >> 2) * T.nn) + col) << 2)) =
+                make_float4(wn[0], wn[1], wn[2], wn[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + r;
+                if (row < fi) a.Wimg[T.img_w + ((((row >> 2) * T.nn) + col) << 2) + (row & 3)] = wn[r];
+                else if (row == fi) a.Wimg[T.img_b + 4 * col] = wn[r];
+            }
         }
     }
     BST(23);
@@ -489,6 +511,21 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
         }
     }
     BST(24);
+}
+
+// flat parameter buffer -> LDS-image twin (after set_params, after a per-layer-path update, or from the
+// post-dropout weights every step)
+__global__ __launch_bounds__(256) void build_image_kernel(const float* __restrict__ Wflat, const int* __restrict__ tab,
+                                                          float* __restrict__ img, int n_f4) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_f4) return;
+    const float4 v = *reinterpret_cast<const float4*>(Wflat + 4L * i);
+    float* d = img + tab[i];                    // consecutive fan-out columns are 4 floats apart in the image
+    d[0] = v.x; d[4] = v.y; d[8] = v.z; d[12] = v.w;
+}
+
+void launch_build_image(hipStream_t s, const float* Wflat, const int* tab, float* img, int n_f4) {
+    hipLaunchKernelGGL(build_image_kernel, dim3((n_f4 + 255) / 256), dim3(256), 0, s, Wflat, tab, img, n_f4);
 }
 
 int dw_opt_blocks(int total_tiles) { return (total_tiles + 3) / 4; }

@@ -91,27 +91,34 @@ struct FinalizeArgs {
 };
 
 // Row-tile fused forward + backward (fused_small.hip)
-struct FusedLayer {
-    const float* W;       // augmented weights in use (post-dropout when dropout < 1)
-    const float* bias;
-    float* out_g;         // layer output, TRANSPOSED [rup16(fo)][ldT] (null for the last decoder layer)
-    float* dpre_g;        // dL/dpre,      TRANSPOSED [rup16(fo)][ldT]
+struct FusedLayer {       // host-side LDS plan of one dense layer
     int fi, fo, ld, act;
     int lds_out, s_out;   // LDS offset / row stride of the layer output tile (floats)
     int lds_w, nn;        // LDS offset of the k-quad interleaved weight image [rup16(fi)/4][nn][4], nn = rup16(fo)+1
     int lds_b;            // LDS offset of the bias vector, stride 4: b[col] at lds_b + 4*col
     int w_off;            // offset of this layer's augmented matrix inside the flat parameter buffer (floats)
 };
+// One GEMM stage of the kernel (forward through a layer, or backward through it): ONE code path runs every
+// stage from this 80-byte record, so the instruction footprint of the kernel is one stage, not 2L+3 of them.
+enum FusedKind : int { FK_FWD_ACT = 0, FK_FWD_HEADS = 1, FK_FWD_BCE = 2, FK_BWD_ACT = 3, FK_BWD_LATENT = 4 };
+struct FusedStage {
+    int in_off, sin, K16, w_off;      // A operand tile (LDS offset, row stride), padded k extent, weight image offset
+    int nn, N, kind, act;             // image column count, valid output columns, FusedKind, activation id
+    int out_off, s_out, b_off, aux_off;   // LDS tile written by the epilogue; bias image; auxiliary tile (x / producing layer's output)
+    int s_aux, NF, trans, pad;        // aux row stride; feature count of the global buffer; 1: sum over fan-out (backward)
+    float* gout; long pad2;           // global [row block][NF][16] buffer the epilogue streams to
+};
+static_assert(sizeof(FusedStage) == 80, "FusedStage is read as five 16-byte LDS words");
 struct FusedArgs {
-    FusedLayer lay[MAX_LAYERS];
+    FusedStage stages[2 * MAX_LAYERS];
+    int n_stages;
     int NL, L, Z, D;
     const float* X; long ldx; int rows;
-    const float* Wflat; int w_total;      // flat parameter buffer in use (post-dropout when dropout < 1)
-    const int* stage_tab;                 // [w_total / 4] LDS float offset of every 16-byte piece of Wflat
+    const float* Wimg; int img_total;     // LDS-image twin of the parameters in use (floats, multiple of 256):
+                                          // copied verbatim to LDS offset 0 by LDS-DMA
     const float* eps_in;
-    float* Zb_g;          // z, TRANSPOSED [rup16(Z)][ldT]
-    float* XT;            // X tile copy, TRANSPOSED [rup16(D)][ldT]
-    long ldT;             // row capacity of the transposed workspace (multiple of 16)
+    float* Zb_g;          // z,       blocked transposed [row block][rup16(Z)][16]
+    float* XT;            // X tile copy, blocked transposed [row block][rup16(D)][16]
     int lds_x, s_x, lds_z, lds_e, s_z, lds_d0, lds_d1, s_d, lds_total;
     uint64_t seed; const DevState* st; long row0_global;
     float lo, hi, inv_batch;
@@ -121,18 +128,20 @@ struct FusedArgs {
 void launch_fused_fwd_bwd(hipStream_t s, const FusedArgs& a);
 
 // dW + optimizer fused (fused_small.hip)
-struct DwOptLayer {
-    const float* A;      // layer input, TRANSPOSED [feature][ldT]
-    const float* B;      // dPre,        TRANSPOSED [feature][ldT]
+struct DwTile {            // one 16x16 tile of one layer's [X | 1]^T . dPre: 64 bytes, read by one scalar load
+    const float* A;      // layer input, blocked transposed [row block][rup16(fi)][16]
+    const float* B;      // dPre,        blocked transposed [row block][rup16(fo)][16]
     long off;            // start of the layer's augmented matrix in the flat parameter buffer
     int fi, fo, ld, l2;
-    int tiles_n, tile_begin;
+    int m0, n0;          // tile origin (fan-in row, fan-out column)
+    int img_w, img_b, nn, pad;   // the layer's weight / bias image offsets and column count in the LDS-image twin
 };
+static_assert(sizeof(DwTile) == 64, "DwTile is read as one 64-byte record");
 struct DwOptArgs {
-    DwOptLayer L[MAX_LAYERS];
-    int n_layers, total_tiles, rows;
-    long ldT;
+    const DwTile* tiles;        // device table, total_tiles records
+    int total_tiles, rows;
     float* W; const float* Wd; const float* mask;
+    float* Wimg;                // LDS-image twin to keep current (null: the caller rebuilds it)
     float* s0; float* s1;
     float* grad_out;
     float* l2_partials;
@@ -145,6 +154,7 @@ struct DwOptArgs {
 void launch_fused_dw_opt(hipStream_t s, const DwOptArgs& a);
 int  dw_opt_blocks(int total_tiles);
 int  fused_set_max_lds(int bytes);
+void launch_build_image(hipStream_t s, const float* Wflat, const int* tab, float* img, int n_f4);
 
 void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a);
 int  gemm_grid_blocks(int kind, const GemmArgs& a);          // number of blocks (= BCE partial count)
