@@ -435,7 +435,23 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         a.M = rows; a.N = y.fo; a.K = y.fi; a.act = y.act; a.Z = Z;
         if (l < NL - 1) {
             a.C = h->out[l]; a.ldc = y.ld;
+#ifdef SMRT_STAMPS
+            static unsigned long long* gdbg = nullptr;
+            if (!gdbg) { (void)hipMalloc((void**)&gdbg, 64); (void)hipMemset(gdbg, 0, 64); }
+            a.dbg = gdbg;
+#endif
             { ProfScope ps(h, PK_FWD); launch_gemm(s, GEMM_NN, EPI_BIAS_ACT, a); } ++launches;
+#ifdef SMRT_STAMPS
+            if (l == 1 && rows >= 4096) {
+                (void)hipStreamSynchronize(s);
+                unsigned long long hb[4];
+                (void)hipMemcpy(hb, gdbg, 32, hipMemcpyDeviceToHost);
+                static int once = 0;
+                if (once++ < 3) fprintf(stderr, "gemm l=1 main loop: %llu shader cycles in %.2f us -> %.3f GHz (M=%d N=%d K=%d)\n",
+                                        hb[0], (double)hb[1] * 0.01, (double)hb[0] / ((double)hb[1] * 10.0), a.M, a.N, a.K);
+                if (once <= 3) fprintf(stderr, "   whole workgroup incl. epilogue: %.2f us\n", (double)hb[3] * 0.01);
+            }
+#endif
             if (l == L) {
                 ProfScope ps(h, PK_REPARAM);
                 launch_reparam(s, h->out[L], y.ld, eps_in, h->Zb, h->Eb, rup4(Z), rows, Z, h->cfg.seed, h->st,

@@ -40,8 +40,22 @@ struct Stage {
 
     // g: operand base; ld: leading dim (floats, % 4 == 0); mn0: tile origin along mn;
     // MN_data: number of real mn entries; k0..: tile origin along k; K: k extent.
+    // full: the whole BMN x BK tile lies inside the matrix (wave-uniform) -> unconditional 16-byte loads.
     __device__ __forceinline__ void load(const float* __restrict__ g, long ld, int mn0, int MN_data,
-                                         int k0, int K, int tid) {
+                                         int k0, int K, int tid, bool full) {
+        if (full) {
+            if constexpr (LAY == INNER) {
+                const float* ptr = g + (long)(mn0 + (tid >> 3)) * ld + k0 + (tid & 7) * 4;
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) r[p] = *reinterpret_cast<const float4*>(ptr + (long)(32 * p) * ld);
+            } else {
+                constexpr int F4 = BMN / 4, RPP = GEMM_THREADS / F4;
+                const float* ptr = g + (long)(k0 + tid / F4) * ld + mn0 + (tid % F4) * 4;
+#pragma unroll
+                for (int p = 0; p < PASSES; ++p) r[p] = *reinterpret_cast<const float4*>(ptr + (long)(RPP * p) * ld);
+            }
+            return;
+        }
         if constexpr (LAY == INNER) {
             const int row = tid >> 3, kq = (tid & 7) * 4;
 #pragma unroll
@@ -143,37 +157,62 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda,
 
     Stage<ALAY, BM, A_ONES> sa;
     Stage<BLAY, BN, false> sb;
-    sa.load(A, lda, m0, M_data, kbeg, kend, tid);
-    sb.load(B, ldb, n0, N_data, kbeg, kend, tid);
+    // Interior tiles (the common case) take unconditional 16-byte loads; the bounds-checked element-wise form costs
+    // ~250 scalar/branch instructions per K-tile, a third of the K-tile's MFMA time.
+    const bool fullA = (m0 + BM <= M_data), fullB = (n0 + BN <= N_data);
+    {
+        const bool fk = (kbeg + BK <= kend);
+        sa.load(A, lda, m0, M_data, kbeg, kend, tid, fullA && fk);
+        sb.load(B, ldb, n0, N_data, kbeg, kend, tid, fullB && fk);
+    }
     sa.store(ldsA, tid);
     sb.store(ldsB, tid);
     __syncthreads();
 
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    // ldsA / ldsB each hold TWO tile images: K-tile t is computed from image t & 1 while the registers staged for
+    // tile t+1 go into the other image, so one barrier per K-tile suffices (the image being overwritten was last
+    // read before the previous barrier).
+    constexpr int SZA = lds_floats<ALAY, BM>(), SZB = lds_floats<BLAY, BN>();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
         const bool more = (k0 + BK) < kend;
         if (more) {
-            sa.load(A, lda, m0, M_data, k0 + BK, kend, tid);
-            sb.load(B, ldb, n0, N_data, k0 + BK, kend, tid);
+            const bool fk = (k0 + 2 * BK <= kend);
+            sa.load(A, lda, m0, M_data, k0 + BK, kend, tid, fullA && fk);
+            sb.load(B, ldb, n0, N_data, k0 + BK, kend, tid, fullB && fk);
         }
+        const float* la = ldsA + buf * SZA;
+        const float* lb = ldsB + buf * SZB;
+        // Fragments of k-block kb+1 are requested before the MFMAs of k-block kb; the asm (which the tile addresses
+        // escape into, so its memory clobber covers them) and the scheduling barrier pin that order.  Left alone,
+        // hipcc sinks each LDS read to just before its MFMA and every group of MFMAs waits out a full LDS latency.
+        float fa[2][WM][4], fb[2][WN][4];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) read_frag<ALAY, BM>(la, wr * 32 * WM + i * 32, 0, r, h, fa[0][i]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) read_frag<BLAY, BN>(lb, wc * 32 * WN + j * 32, 0, r, h, fb[0][j]);
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
-            float fa[WM][4], fb[WN][4];
+            const int cur = kb & 1, nxt = cur ^ 1;
+            if (kb + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) read_frag<ALAY, BM>(ldsA, wr * 32 * WM + i * 32, kb, r, h, fa[i]);
+                for (int i = 0; i < WM; ++i) read_frag<ALAY, BM>(la, wr * 32 * WM + i * 32, kb + 1, r, h, fa[nxt][i]);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) read_frag<BLAY, BN>(ldsB, wc * 32 * WN + j * 32, kb, r, h, fb[j]);
+                for (int j = 0; j < WN; ++j) read_frag<BLAY, BN>(lb, wc * 32 * WN + j * 32, kb + 1, r, h, fb[nxt][j]);
+            }
+            asm volatile("" :: "v"(ldsA), "v"(ldsB) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
         if (more) {
-            sa.store(ldsA, tid);
-            sb.store(ldsB, tid);
+            sa.store(ldsA + (buf ^ 1) * SZA, tid);
+            sb.store(ldsB + (buf ^ 1) * SZB, tid);
             __syncthreads();
         }
     }

@@ -18,19 +18,53 @@ namespace smrt {
 template <int ALAY, int BLAY, int WM, int WN, int EPI>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    __shared__ __align__(16) float ldsA[lds_floats<ALAY, BM>()];
-    __shared__ __align__(16) float ldsB[lds_floats<BLAY, BN>()];
+    __shared__ __align__(16) float ldsA[2 * lds_floats<ALAY, BM>()];      // two tile images each (gemm_tile)
+    __shared__ __align__(16) float ldsB[2 * lds_floats<BLAY, BN>()];
     __shared__ float red[4];
 
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so XCD x
+    // takes the x-th contiguous chunk of the row-major tile list: the column tiles that re-read one row block
+    // of A then share an L2 instead of pulling it over the fabric eight times.  Bijective for any grid size.
+    int m0, n0;
+    {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, nwg = gridDim.x * gridDim.y;
+        const int xcd = lin & 7, idx = lin >> 3, qq = nwg >> 3, rr = nwg & 7;
+        const int t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+        m0 = (t / (int)gridDim.x) * BM; n0 = (t % (int)gridDim.x) * BN;
+    }
+#ifdef SMRT_STAMPS
+    const unsigned long long c_beg = clock64(), w_beg = wall_clock64();
+#endif
     f32x16 acc[WM][WN];
     gemm_tile<ALAY, BLAY, WM, WN, false>(a.A, a.lda, a.M, a.B, a.ldb, a.N, m0, n0, 0, a.K, ldsA, ldsB, acc);
 
+#ifdef SMRT_STAMPS
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 1) {     // main-loop clock of one workgroup
+        a.dbg[0] = clock64() - c_beg; a.dbg[1] = wall_clock64() - w_beg;
+    }
+#endif
     if constexpr (EPI == EPI_BIAS_ACT) {
         // y = act(x.W + b)                                                     layer.py:368
-        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-            if (row < a.M && col < a.N) a.C[(long)row * a.ldc + col] = act_fwd(a.act, v + a.bias[col]);
-        });
+        // The bias is fetched once per column (the stores to C may alias it as far as the compiler knows, so inside
+        // the element loop it would be re-loaded 16 times) and interior tiles skip the bounds checks.
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float bj[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + (wave & 1) * 32 * WN + j * 32 + (lane & 31);
+            bj[j] = (col < a.N) ? a.bias[col] : 0.0f;
+        }
+        if (m0 + BM <= a.M && n0 + BN <= a.N) {
+            for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+                const int j = ((col - n0) >> 5) % WN;
+                a.C[(long)row * a.ldc + col] = act_fwd(a.act, v + bj[j]);
+            });
+        } else {
+            for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+                const int j = ((col - n0) >> 5) % WN;
+                if (row < a.M && col < a.N) a.C[(long)row * a.ldc + col] = act_fwd(a.act, v + bj[j]);
+            });
+        }
     } else if constexpr (EPI == EPI_HEADS_SPLIT) {
         // fused (z_mean | z_log_sigma) heads written to two contiguous [n][Z] outputs   autoencoder.py:500
         for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
@@ -63,10 +97,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
         if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
     } else if constexpr (EPI == EPI_ACTGRAD) {
         // dPre_prev = (dPre . W^T) * act'(y_prev)
-        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-            if (row < a.M && col < a.N)
+        if (m0 + BM <= a.M && n0 + BN <= a.N) {
+            for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
                 a.C[(long)row * a.ldc + col] = act_bwd(a.act, a.aux[(long)row * a.ldaux + col], v);
-        });
+            });
+        } else {
+            for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+                if (row < a.M && col < a.N)
+                    a.C[(long)row * a.ldc + col] = act_bwd(a.act, a.aux[(long)row * a.ldaux + col], v);
+            });
+        }
     } else if constexpr (EPI == EPI_LATENT) {
         // v = dL/dz.  Through the reparameterisation and the KL term into both heads:
         //   dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B     layer.py:279, _ae_utils.py:49
@@ -82,6 +122,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
             }
         });
     }
+#ifdef SMRT_STAMPS
+    __syncthreads();
+    if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 1) {
+        a.dbg[2] = clock64() - c_beg; a.dbg[3] = wall_clock64() - w_beg;
+    }
+#endif
 }
 
 static inline bool use_big_tiles(int M, int N) {
@@ -123,8 +169,8 @@ void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a) {
 template <int WM, int WN>
 __global__ __launch_bounds__(GEMM_THREADS) void dw_kernel(const DwArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    __shared__ __align__(16) float ldsA[lds_floats<OUTER, BM>()];
-    __shared__ __align__(16) float ldsB[lds_floats<OUTER, BN>()];
+    __shared__ __align__(16) float ldsA[2 * lds_floats<OUTER, BM>()];
+    __shared__ __align__(16) float ldsB[2 * lds_floats<OUTER, BN>()];
 
     const int t = blockIdx.x;
     int li = 0;

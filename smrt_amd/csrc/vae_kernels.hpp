@@ -28,6 +28,7 @@ struct GemmArgs {
     float* partials;                    // BCE: one partial loss sum per block
     int act, Z;
     float lo, hi, inv_batch;
+    unsigned long long* dbg;            // diagnostic builds only (-DSMRT_STAMPS)
 };
 
 struct DwLayer {
