@@ -66,6 +66,23 @@ def kind_work(rows_per_epoch, steps_per_epoch):
     }
 
 
+def measured_traffic(kind):
+    """HBM bytes per launch of kernel `kind` from the newest committed PMC summary (profiles/*_traffic.json, written
+    by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md).  None when no summary names the kernel."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            ks = json.load(open(path)).get("kernels", {})
+        except Exception:
+            continue
+        for name, rec in ks.items():
+            if name.startswith(kind):
+                best = float(rec["hbm_bytes_per_launch"])
+    return best
+
+
 def cpu_baseline(X, seconds_budget=12.0):
     """The CPU restatement of the reference path (oracle, numpy fp32, per-step Python loop like base.py:202-217)
     timed on a bounded sample of the same workload."""
@@ -89,12 +106,59 @@ def cpu_baseline(X, seconds_budget=12.0):
                       % (epochs, len(X), BATCH, epochs * ((len(X) + BATCH - 1) // BATCH), dt)}
 
 
+def tabular_c2(n=1000000, n_minor=N_MINORITY, seed=42):
+    """The whole C2 input: n x 64 fp32, binary labels 1:50, features sigmoid(N(mu_class, 1))."""
+    rs = np.random.RandomState(seed)
+    y = np.zeros(n, dtype=np.int64)
+    y[rs.choice(n, n_minor, replace=False)] = 1
+    mu = rs.normal(size=(2, D)).astype(np.float32)
+    X = rs.normal(size=(n, D)).astype(np.float32)
+    X += mu[y]
+    return 1.0 / (1.0 + np.exp(-X)), y
+
+
+def balance_wallclock(with_cpu):
+    """End-to-end smrt_balance(X, y, 128, 16) on C2, host arrays in -> host arrays out (API defaults: 20 epochs, batch
+    128, rms_prop, balance_ratio 0.2 -> 176 470 synthetic rows, shuffled fp64 output of 1 176 470 x 64).  Median of 3 after
+    one warm-up call; the CPU leg runs the oracle's restatement of the same call once."""
+    from smrt_amd.balance import smrt_balance
+    X, y = tabular_c2()
+    kw = dict(n_hidden=HIDDEN, n_latent_factors=Z, balance_ratio=0.2, random_state=42)
+    smrt_balance(X[:50000], y[:50000], **kw)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        Xb, yb = smrt_balance(X, y, **kw)
+        times.append(time.perf_counter() - t0)
+    out = {"workload": "C2: smrt_balance on 1M x 64 fp32, 1:50 -> %d x %d fp64" % Xb.shape, "wall_s": float(np.median(times)),
+           "rows_out": int(Xb.shape[0]), "minority_out": int((yb == 1).sum())}
+    if with_cpu:
+        from oracle.balance_oracle import balance
+        from oracle.vae_oracle import OracleVAE
+
+        class Est(object):
+            def __init__(self, X_sub, rs):
+                self.rs = rs
+                self.o = OracleVAE(D, HIDDEN, Z, seed=42)
+                self.o.fit(X_sub, n_epochs=20, batch_size=BATCH)
+
+            def generate(self, n=1, **nrm):
+                return self.o.generate(self.rs, n, **nrm)
+
+        t0 = time.perf_counter()
+        Xc, yc = balance(X, y, Est, balance_ratio=0.2, random_state=42)
+        out["cpu_port_wall_s"] = time.perf_counter() - t0
+        assert Xc.shape == Xb.shape
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-balance", action="store_true", help="skip the end-to-end smrt_balance wall-clock leg")
     args = ap.parse_args()
 
     import torch
@@ -158,7 +222,9 @@ def main():
         achieved = w["bytes"] / w["launches"] / (pk["avg_us"] * 1e-6) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": achieved / PEAK_HBM_GBS, "traffic": None}
-    roof.update({"kernel": dom, "avg_launch_us": pk["avg_us"], "launches_per_step": pk["launches_per_epoch"]})
+    roof["traffic"] = measured_traffic(dom)
+    roof.update({"kernel": dom, "avg_launch_us": pk["avg_us"], "launches_per_step": pk["launches_per_epoch"],
+                 "algorithmic_per_launch": w.get("flops", w.get("bytes")) / w["launches"]})
 
     if rank == 0:
         out = {
@@ -178,6 +244,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X)
+        if world == 1 and not args.no_balance:
+            sess.close()
+            out["smrt_balance"] = balance_wallclock(with_cpu=not args.no_cpu_baseline)
         print(json.dumps(out))
     sess.close()
     if dist is not None:

@@ -139,6 +139,16 @@ enum { SMRT_PK_DROPOUT = 0, SMRT_PK_FWD, SMRT_PK_FWD_BCE, SMRT_PK_REPARAM, SMRT_
 int  smrt_vae_profile_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n_rows, int32_t batch_size,
                              int32_t n_epochs, double* ms_by_kind, int64_t* launches_by_kind);
 
+/* Host-side output assembly of smrt_balance: replaces the reference's X.copy() + per-class np.vstack + shuffle gather
+ * (smrt/balance/smrt.py:184,237,244-250) with ONE multi-threaded pass.  All pointers are HOST memory.
+ *   out[i][:] = fp64( row order[i] of the virtual concatenation [X (n_orig rows) ; synth (n_synth fp32 rows)] )
+ *   X: fp32 (x_is_f32 != 0) or fp64, row stride ldx elements; synth row stride ld_synth; out [n_out][d] contiguous;
+ *   order: n_out row numbers in [0, n_orig + n_synth), or NULL for the identity (then n_out == n_orig + n_synth).
+ * Returns 0, or -1 on a bad argument (nothing is written). */
+int  smrt_assemble_rows(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,
+                        const float* synth, int64_t n_synth, int64_t ld_synth,
+                        const int64_t* order, int64_t n_out, double* out, int32_t n_threads);
+
 const char* smrt_last_error(void);
 const char* smrt_version(void);
 

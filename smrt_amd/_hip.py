@@ -27,7 +27,7 @@ EXPORTS = [
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
-    "smrt_last_error", "smrt_version",
+    "smrt_assemble_rows", "smrt_last_error", "smrt_version",
 ]
 
 
@@ -90,6 +90,7 @@ def load():
     lib.smrt_vae_generate.argtypes = [vp, i64, C.c_uint64, C.c_float, C.c_float, vp, i64]
     lib.smrt_vae_sample_eps.argtypes = [vp, i64, i64, i32, vp]
     lib.smrt_vae_profile_epochs.argtypes = [vp, vp, i64, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(i64)]
+    lib.smrt_assemble_rows.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32]
     _lib = lib
     return lib
 
@@ -125,6 +126,33 @@ def to_device_padded(array, device):
         t[:, :d] = torch.from_numpy(a).to(device)
     torch.cuda.synchronize(device)
     return t, ld
+
+
+def assemble_rows(X, synth, order, n_threads=None):
+    """fp64 ``[X ; synth][order]`` in one multi-threaded pass (``order`` None: plain concatenation).
+
+    ``X``: C-contiguous fp32/fp64 ``[n, d]``; ``synth``: fp32 ``[m, d]`` (may have 0 rows); ``order``: int64 row numbers.
+    Host-only: needs the library, not a GPU."""
+    lib = load()
+    X = np.ascontiguousarray(X)
+    if X.dtype not in (np.float32, np.float64):
+        X = X.astype(np.float64)
+    synth = np.ascontiguousarray(synth, dtype=np.float32)
+    n, d = X.shape
+    m = synth.shape[0]
+    if m and synth.shape[1] != d:
+        raise ValueError("synthetic rows have %d columns, X has %d" % (synth.shape[1], d))
+    if order is not None:
+        order = np.ascontiguousarray(order, dtype=np.int64)
+    n_out = n + m if order is None else order.shape[0]
+    out = np.empty((n_out, d), dtype=np.float64)
+    if n_threads is None:
+        n_threads = max(1, min(16, os.cpu_count() or 1))
+    rc = lib.smrt_assemble_rows(X.ctypes.data, int(X.dtype == np.float32), n, d, d, synth.ctypes.data if m else None, m, d,
+                                order.ctypes.data if order is not None else None, n_out, out.ctypes.data, int(n_threads))
+    if rc != 0:
+        raise HipLibraryError("smrt_assemble_rows rejected its arguments (%d)" % rc)
+    return out
 
 
 class VaeHandle(object):

@@ -14,17 +14,19 @@ MAX_N_CLASSES = 100     # most distinct labels a balancer accepts
 MIN_N_SAMPLES = 2       # fewest rows any class may have
 
 
-def validate_X_y_ratio_classes(X, y, ratio):
+def validate_X_y_ratio_classes(X, y, ratio, copy=True, keep_float32=False):
     """Check inputs and derive the class bookkeeping every balancer needs.
 
     Returns ``(X, y, n_classes, present_classes, counts, majority_label, target_count)`` where ``X`` is a
-    fresh fp64 copy, ``present_classes``/``counts`` come from ``np.unique`` (sorted labels), the majority
+    fresh fp64 copy (``copy=False``: no copy when ``X`` already is a C-contiguous fp64 array; ``keep_float32``: an fp32
+    array is validated as it is -- ``smrt_balance`` converts while it writes its output, in one pass), ``present_classes``/``counts`` come from ``np.unique`` (sorted labels), the majority
     is the FIRST class with the largest count and ``target_count = max(int(ratio * majority_count), 1)``.
     Raises ``ValueError`` for a ratio outside (0, 1], a target that is not binary/multiclass, more than
     ``MAX_N_CLASSES`` labels, or a class with fewer than ``MIN_N_SAMPLES`` rows.
     """
     validate_float(ratio, "balance_ratio")
-    X = check_array(X, accept_sparse=False, dtype=NPDTYPE, ensure_2d=True, copy=True)
+    dtype = [np.float64, np.float32] if (keep_float32 and getattr(X, "dtype", None) == np.float32) else NPDTYPE
+    X = check_array(X, accept_sparse=False, dtype=dtype, ensure_2d=True, copy=copy, order="C")
     y = column_or_1d(check_array(y, accept_sparse=False, ensure_2d=False, dtype=None), warn=False)
 
     kind = type_of_target(y)

@@ -6,8 +6,11 @@ values, same consumption order of the ONE shared numpy stream (per class: ``choi
 
 What is different under the hood:
   * every VAE trains and generates through the HIP library (``smrt_amd.autoencode``);
-  * the output slab is allocated once and each class writes its block in place (the reference
-    re-copies the whole matrix per class, smrt.py:237);
+  * the balanced matrix is written ONCE: the input is validated in place (no fp64 copy up front), the
+    synthetic blocks are collected in one fp32 slab, and ``smrt_assemble_rows`` (multi-threaded C++, host
+    side of the library) writes ``fp64([X ; synthetic][order])`` in a single pass -- the reference makes two
+    full copies of X, re-copies the whole matrix per class and gathers it again for the shuffle
+    (base.py:24, smrt.py:184,237,248-250);
   * under ``torch.distributed`` (one process per GPU) the independent per-class jobs are sharded
     across ranks, longest job first, with no collective on the data path; the finished blocks are
     exchanged once at the end.  The result is identical for any world size because ranks that do
@@ -20,6 +23,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from .. import _hip
 from ..autoencode import VariationalAutoEncoder
 from ..autoencode.topography import resolve_latent
 from ..utils import DEFAULT_SEED, get_random_state
@@ -86,7 +90,7 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
     ``return_estimators``.
     """
     X, y, n_classes, present_classes, counts, majority_label, target_count = \
-        validate_X_y_ratio_classes(X, y, balance_ratio)
+        validate_X_y_ratio_classes(X, y, balance_ratio, copy=False, keep_float32=True)
 
     seeded_random_state = get_random_state(random_state)
     random_state = seeded_random_state.state
@@ -114,20 +118,19 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
     rank, world, dist = _dist()
     owners = plan_class_jobs([n_sub * max(int(n_epochs), 1) + need for _, _, n_sub, need in jobs], world)
 
-    n_total = n_orig + sum(j[3] for j in jobs)
-    X_out = np.empty((n_total, n_features), dtype=np.float64)
-    X_out[:n_orig] = X
+    n_synth = sum(j[3] for j in jobs)
+    n_total = n_orig + n_synth
+    synth = np.empty((n_synth, n_features), dtype=np.float32)      # what the kernels produce (fp32, autoencoder.py:517)
     y_out_codes = np.empty(n_total, dtype=y_codes.dtype)
     y_out_codes[:n_orig] = y_codes
 
     # ---- per-class train-then-generate (smrt.py:197-238); class order fixes the stream order
-    blocks, cursor = [], n_orig
+    blocks, cursor = [], 0
     for j, (code, label, n_sub, need) in enumerate(jobs):
         mine = owners[j] == rank
         X_sub = X[y_codes == code, :]
         encoder = prefit_estimators.get(label, None)
         fresh = encoder is None
-        synthetic = None
         if mine:
             if fresh:
                 encoder = VariationalAutoEncoder(
@@ -143,8 +146,7 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
             else:
                 sample_idcs = random_state.choice(np.arange(n_sub), size=need, replace=True)
                 synthetic = encoder.generate_from_sample(X_sub[sample_idcs, :], **generate_args)
-            synthetic = np.asarray(synthetic)
-            X_out[cursor:cursor + need] = synthetic
+            synth[cursor:cursor + need] = np.asarray(synthetic)
         else:
             # another rank owns this class: consume exactly the draws it makes on the shared stream
             if gen_from_samples:
@@ -153,21 +155,23 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
             if shares_stream:
                 z_dim = resolve_latent(n_latent_factors, n_features) if fresh else int(encoder.n_latent_factors)
                 random_state.normal(size=(need, z_dim))
-        blocks.append((cursor, need, owners[j], synthetic))
-        y_out_codes[cursor:cursor + need] = code
+        blocks.append((cursor, need, owners[j], mine))
+        y_out_codes[n_orig + cursor:n_orig + cursor + need] = code
         cursor += need
 
     if world > 1:
-        for start, need, owner, synthetic in blocks:
-            got = _exchange_block(dist, synthetic, (need, n_features), owner)
-            if owner != rank:
-                X_out[start:start + need] = got
+        for start, need, owner, mine in blocks:
+            got = _exchange_block(dist, synth[start:start + need] if mine else None, (need, n_features), owner)
+            if not mine:
+                synth[start:start + need] = got
 
     y_out = present_classes[y_out_codes]                  # back to the caller's label space (smrt.py:241)
 
+    output_order = None
     if shuffle:
         output_order = random_state.permutation(np.arange(n_total))
-        X_out, y_out = X_out[output_order, :], y_out[output_order]
+        y_out = y_out[output_order]
+    X_out = _hip.assemble_rows(X, synth, output_order)    # fp64 [X ; synthetic][order] in one pass
 
     if return_estimators:
         return X_out, y_out, encoders

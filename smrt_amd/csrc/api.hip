@@ -13,6 +13,7 @@
 using namespace smrt;
 
 static thread_local std::string g_err;
+namespace smrt { thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr; }
 static int fail(int code, const std::string& m) { g_err = m; return code; }
 
 #define HIPC(expr)                                                                              \
@@ -110,11 +111,12 @@ struct ProfScope {
             for (int i = 0; i < 2; ++i) { hipEvent_t e; (void)hipEventCreate(&e); h->prof_pool.push_back(e); }
         }
         h->prof_kind.push_back(kind);
-        (void)hipEventRecord(h->prof_pool[h->prof_used], h->stream);
+        g_prof_start = h->prof_pool[h->prof_used];           // stamped by the launch itself (SMRT_LAUNCH)
+        g_prof_stop = h->prof_pool[h->prof_used + 1];
     }
     ~ProfScope() {
         if (!h->prof) return;
-        (void)hipEventRecord(h->prof_pool[h->prof_used + 1], h->stream);
+        g_prof_start = g_prof_stop = nullptr;
         h->prof_used += 2;
     }
 };

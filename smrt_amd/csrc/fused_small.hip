@@ -344,7 +344,7 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
 
 void launch_fused_fwd_bwd(hipStream_t s, const FusedArgs& a) {
     const int grid = (a.rows + FTM - 1) / FTM;
-    hipLaunchKernelGGL(fused_fwd_bwd_kernel, dim3(grid), dim3(FTHREADS), (size_t)a.lds_total * sizeof(float), s, a);
+    SMRT_LAUNCH(fused_fwd_bwd_kernel, dim3(grid), dim3(FTHREADS), (size_t)a.lds_total * sizeof(float), s, a);
 }
 
 int fused_set_max_lds(int bytes) {
@@ -525,13 +525,13 @@ __global__ __launch_bounds__(256) void build_image_kernel(const float* __restric
 }
 
 void launch_build_image(hipStream_t s, const float* Wflat, const int* tab, float* img, int n_f4) {
-    hipLaunchKernelGGL(build_image_kernel, dim3((n_f4 + 255) / 256), dim3(256), 0, s, Wflat, tab, img, n_f4);
+    SMRT_LAUNCH(build_image_kernel, dim3((n_f4 + 255) / 256), dim3(256), 0, s, Wflat, tab, img, n_f4);
 }
 
 int dw_opt_blocks(int total_tiles) { return (total_tiles + 3) / 4; }
 
 void launch_fused_dw_opt(hipStream_t s, const DwOptArgs& a) {
-    hipLaunchKernelGGL(fused_dw_opt_kernel, dim3(dw_opt_blocks(a.total_tiles)), dim3(BTHREADS), 0, s, a);
+    SMRT_LAUNCH(fused_dw_opt_kernel, dim3(dw_opt_blocks(a.total_tiles)), dim3(BTHREADS), 0, s, a);
 }
 
 }  // namespace smrt

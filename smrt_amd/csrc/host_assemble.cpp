@@ -1,0 +1,63 @@
+// Host-side output assembly of smrt_balance (plain C++, no device code).
+//
+// The reference builds its result with two full fp64 copies of X (smrt/balance/base.py:24, smrt/balance/smrt.py:184), one
+// np.vstack per class (smrt.py:237) and a fancy-index gather for the shuffle (smrt.py:248-250): at 1M+ rows that
+// is what is left of the wall-clock once the VAE runs on the GPU.  Here the balanced matrix is written ONCE:
+// output row i is row order[i] of the virtual concatenation [X ; synthetic], converted to fp64 on the fly, by a
+// pool of threads that each own a contiguous range of output rows.
+#include "../../include/smrt_hip.h"
+
+#include <algorithm>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+template <class SRC>
+inline void put_row(const SRC* src, double* dst, int64_t d) {
+    for (int64_t j = 0; j < d; ++j) dst[j] = (double)src[j];
+}
+template <>
+inline void put_row<double>(const double* src, double* dst, int64_t d) {
+    std::memcpy(dst, src, sizeof(double) * (size_t)d);
+}
+
+template <class SRC>
+void assemble_range(const SRC* X, int64_t n_orig, int64_t d, int64_t ldx, const float* synth, int64_t ld_synth,
+                    const int64_t* order, int64_t lo, int64_t hi, double* out) {
+    for (int64_t i = lo; i < hi; ++i) {
+        const int64_t r = order ? order[i] : i;
+        double* dst = out + i * d;
+        if (r < n_orig) put_row<SRC>(X + r * ldx, dst, d);
+        else            put_row<float>(synth + (r - n_orig) * ld_synth, dst, d);
+    }
+}
+
+}  // namespace
+
+extern "C" int smrt_assemble_rows(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,
+                                  const float* synth, int64_t n_synth, int64_t ld_synth,
+                                  const int64_t* order, int64_t n_out, double* out, int32_t n_threads) {
+    if ((!X && n_orig > 0) || (!synth && n_synth > 0) || !out) return -1;
+    if (n_orig < 0 || n_synth < 0 || d < 1 || ldx < d || (n_synth > 0 && ld_synth < d) || n_out < 0) return -1;
+    if (!order && n_out != n_orig + n_synth) return -1;
+    if (order)
+        for (int64_t i = 0; i < n_out; ++i)
+            if (order[i] < 0 || order[i] >= n_orig + n_synth) return -1;      // never read outside the inputs
+    const int64_t min_rows = 4096;                                        // below this a thread is not worth starting
+    int nt = std::max(1, (int)std::min<int64_t>(n_threads, (n_out + min_rows - 1) / min_rows));
+    auto run = [&](int64_t lo, int64_t hi) {
+        if (x_is_f32) assemble_range<float>((const float*)X, n_orig, d, ldx, synth, ld_synth, order, lo, hi, out);
+        else          assemble_range<double>((const double*)X, n_orig, d, ldx, synth, ld_synth, order, lo, hi, out);
+    };
+    if (nt == 1) { run(0, n_out); return 0; }
+    std::vector<std::thread> pool;
+    const int64_t per = (n_out + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t lo = t * per, hi = std::min<int64_t>(n_out, lo + per);
+        if (lo < hi) pool.emplace_back(run, lo, hi);
+    }
+    for (auto& th : pool) th.join();
+    return 0;
+}

@@ -145,10 +145,10 @@ template <int ALAY, int BLAY, int EPI>
 static void launch_gemm_t(hipStream_t s, const GemmArgs& a) {
     if (use_big_tiles(a.M, a.N)) {
         dim3 grid((a.N + 127) / 128, (a.M + 127) / 128);
-        hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, 2, 2, EPI>), grid, dim3(GEMM_THREADS), 0, s, a);
+        SMRT_LAUNCH((gemm_kernel<ALAY, BLAY, 2, 2, EPI>), grid, dim3(GEMM_THREADS), 0, s, a);
     } else {
         dim3 grid((a.N + 63) / 64, (a.M + 63) / 64);
-        hipLaunchKernelGGL((gemm_kernel<ALAY, BLAY, 1, 1, EPI>), grid, dim3(GEMM_THREADS), 0, s, a);
+        SMRT_LAUNCH((gemm_kernel<ALAY, BLAY, 1, 1, EPI>), grid, dim3(GEMM_THREADS), 0, s, a);
     }
 }
 
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void dw_kernel(const DwArgs a) {
 
 void launch_dw(hipStream_t s, const DwArgs& a, bool big) {
     dim3 grid(a.total_tiles, a.splits);
-    if (big) hipLaunchKernelGGL((dw_kernel<2, 2>), grid, dim3(GEMM_THREADS), 0, s, a);
-    else     hipLaunchKernelGGL((dw_kernel<1, 1>), grid, dim3(GEMM_THREADS), 0, s, a);
+    if (big) SMRT_LAUNCH((dw_kernel<2, 2>), grid, dim3(GEMM_THREADS), 0, s, a);
+    else     SMRT_LAUNCH((dw_kernel<1, 1>), grid, dim3(GEMM_THREADS), 0, s, a);
 }
 
 // =====================================================================================
@@ -226,7 +226,7 @@ int reparam_blocks(int rows, int Z) { return (int)(((long)rows * Z + 255) / 256)
 
 void launch_reparam(hipStream_t s, const float* ML, long ldml, const float* eps_in, float* Zb, float* Eb, long ldz,
                     int rows, int Z, uint64_t seed, const DevState* st, long row0_global, float* kl_partials) {
-    hipLaunchKernelGGL(reparam_kernel, dim3(reparam_blocks(rows, Z)), dim3(256), 0, s, ML, ldml, eps_in, Zb, Eb, ldz,
+    SMRT_LAUNCH(reparam_kernel, dim3(reparam_blocks(rows, Z)), dim3(256), 0, s, ML, ldml, eps_in, Zb, Eb, ldz,
                        rows, Z, seed, st, row0_global, kl_partials);
 }
 
@@ -244,7 +244,7 @@ void launch_sample_normal(hipStream_t s, float* out, long ld, long rows, int col
                           uint32_t step, uint64_t elem0, float loc, float scale) {
     const long n = rows * cols;
     if (n <= 0) return;
-    hipLaunchKernelGGL(sample_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, ld, rows, cols,
+    SMRT_LAUNCH(sample_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, ld, rows, cols,
                        seed, stream, step, elem0, loc, scale);
 }
 
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const DropArgs a) {
 }
 
 void launch_dropout(hipStream_t s, const DropArgs& a) {
-    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((a.P + 255) / 256)), dim3(256), 0, s, a);
+    SMRT_LAUNCH(dropout_kernel, dim3((unsigned)((a.P + 255) / 256)), dim3(256), 0, s, a);
 }
 
 // =====================================================================================
@@ -380,7 +380,7 @@ int optimizer_blocks(long P) { return (int)((P / 4 + 255) / 256); }
 void launch_optimizer(hipStream_t s, const OptArgs& a, int* n_blocks_out) {
     const int nb = optimizer_blocks(a.P);
     if (n_blocks_out) *n_blocks_out = nb;
-    hipLaunchKernelGGL(optimizer_kernel, dim3(nb), dim3(256), 0, s, a);
+    SMRT_LAUNCH(optimizer_kernel, dim3(nb), dim3(256), 0, s, a);
 }
 
 // Sum the split-K slabs into one contiguous gradient (data-parallel path hands this to the all-reduce).
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 
 void launch_reduce_slabs(hipStream_t s, const float* G, int splits, long slab_stride, long P, float* out) {
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(optimizer_blocks(P)), dim3(256), 0, s, G, splits, slab_stride, P, out);
+    SMRT_LAUNCH(reduce_slabs_kernel, dim3(optimizer_blocks(P)), dim3(256), 0, s, G, splits, slab_stride, P, out);
 }
 
 // =====================================================================================
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
 }
 
 void launch_finalize(hipStream_t s, const FinalizeArgs& a) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, a);
+    SMRT_LAUNCH(finalize_kernel, dim3(1), dim3(256), 0, s, a);
 }
 
 }  // namespace smrt

@@ -1,11 +1,22 @@
 // Kernel argument blocks and launcher declarations (host <-> vae_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace smrt {
 
 constexpr int MAX_LAYERS = 16;      // internal dense layers: 2*L + 2 <= 14
+
+// Per-kernel timing (smrt_vae_profile_epochs): when the host thread has set an event pair, the next launch goes
+// through hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin / end times (what
+// rocprofv3 --kernel-trace reports), not with the time a separately recorded event happens to retire.
+extern thread_local hipEvent_t g_prof_start, g_prof_stop;
+#define SMRT_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                   \
+    do {                                                                                                      \
+        if (g_prof_start) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, g_prof_start, g_prof_stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                             \
+    } while (0)
 
 // Device-resident scalars that change every step (read by kernels so a captured graph replays).
 struct DevState {

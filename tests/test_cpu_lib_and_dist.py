@@ -110,3 +110,28 @@ def test_smrt_balance_shards_classes_across_ranks(tmp_path):
         owned.append(d["gen_owned"])
     # every class job ran on exactly one rank, and both ranks got work
     assert np.array_equal(owned[0] ^ owned[1], np.ones(3, bool)) and owned[0].any() and owned[1].any()
+
+
+def test_assemble_rows_matches_numpy():
+    """smrt_assemble_rows (host side of the library): fp64([X ; synth][order]) for fp32 / fp64 / other inputs, identity
+    order, no synthetic rows, many threads vs one, and rejected out-of-range row numbers."""
+    from smrt_amd import _hip
+    rs = np.random.RandomState(4)
+    S = rs.uniform(size=(37, 5)).astype(np.float32)
+    for X in (rs.uniform(size=(101, 5)), rs.uniform(size=(101, 5)).astype(np.float32), rs.randint(0, 9, size=(101, 5))):
+        ref = np.vstack([np.asarray(X, np.float64), S.astype(np.float64)])
+        order = rs.permutation(138)
+        for nt in (1, 3):
+            got = _hip.assemble_rows(X, S, order, nt)
+            assert got.dtype == np.float64 and np.array_equal(got, ref[order])
+        assert np.array_equal(_hip.assemble_rows(X, S, None), ref)
+        assert np.array_equal(_hip.assemble_rows(X, S[:0], None), ref[:101])
+        assert np.array_equal(_hip.assemble_rows(X, S, order[:10]), ref[order[:10]])
+    big = rs.uniform(size=(20000, 3)).astype(np.float32)                 # enough rows for several threads
+    order = rs.permutation(20037)
+    assert np.array_equal(_hip.assemble_rows(big, S[:, :3], order, 8),
+                          np.vstack([big.astype(np.float64), S[:, :3].astype(np.float64)])[order])
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.assemble_rows(big, S[:, :3], np.array([0, 20037]))
+    with pytest.raises(ValueError):
+        _hip.assemble_rows(big, S, None)
