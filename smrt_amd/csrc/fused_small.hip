@@ -103,15 +103,12 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
         const int r = tid / xf4_per_row, c4 = (tid - r * xf4_per_row) << 2;
         xv = *reinterpret_cast<const float4*>(a.X + (long)(r0 + r) * a.ldx + c4);
     }
-    // epsilon of the reparameterisation depends on (seed, step, row) only: injected values are fetched, Philox
-    // values are computed, while the weight image is still in flight
-    float eps_pre[2] = {0.f, 0.f};
+    float eps_pre[2] = {0.f, 0.f};                         // injected epsilon: fetched with the other loads
+    if (a.eps_in) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = tid + u * FTHREADS;
-        if (i < rows_here * Z) {
-            if (a.eps_in) eps_pre[u] = a.eps_in[(long)r0 * Z + i];
-            else          eps_pre[u] = philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + r0) * Z + i);
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * FTHREADS;
+            if (i < rows_here * Z) eps_pre[u] = a.eps_in[(long)r0 * Z + i];
         }
     }
     {
@@ -312,8 +309,7 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
                 if (r < rows_here) {
                     const float mu = o[r * s_out + k], ls = o[r * s_out + Z + k];
                     float e;
-                    if (u < 2) e = (u == 0) ? eps_pre[0] : eps_pre[1];
-                    else if (a.eps_in) e = a.eps_in[(long)r0 * Z + i];
+                    if (a.eps_in) e = (u == 0) ? eps_pre[0] : (u == 1 ? eps_pre[1] : a.eps_in[(long)r0 * Z + i]);
                     else e = philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + r0) * Z + i);
                     const float el = __expf(ls);
                     z = mu + e * el;
