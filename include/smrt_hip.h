@@ -39,6 +39,10 @@ enum { SMRT_ACT_ELU = 0, SMRT_ACT_IDENTITY = 1, SMRT_ACT_RELU = 2, SMRT_ACT_SIGM
 enum { SMRT_OPT_SGD = 0, SMRT_OPT_RMSPROP = 1, SMRT_OPT_ADAM = 2, SMRT_OPT_ADAGRAD = 3,
        SMRT_OPT_ADADELTA = 4, SMRT_OPT_PROXIMAL_SGD = 5, SMRT_OPT_PROXIMAL_ADAGRAD = 6 };
 
+/* smrt/autoencode/autoencoder.py:285 (VariationalAutoEncoder) / :91 (AutoEncoder: symmetric encoder/decoder, the
+ * user's activation on every layer, loss = mean over all B*D elements of (x - x_hat)^2, autoencoder.py:260). */
+enum { SMRT_MODEL_VAE = 0, SMRT_MODEL_AE = 1 };
+
 #define SMRT_MAX_HIDDEN 6
 
 typedef struct smrt_vae_cfg {
@@ -56,6 +60,9 @@ typedef struct smrt_vae_cfg {
     float    dropout_keep;               /* (0,1]; dropout acts on the WEIGHTS, layer.py:365 */
     uint64_t seed;                       /* Philox key for epsilon / dropout / fast generate */
     int32_t  max_batch;                  /* rows per training step the workspace is sized for */
+    int32_t  model;                      /* SMRT_MODEL_*; for SMRT_MODEL_AE n_latent, bce_lo/hi are ignored, the flat
+                                          * parameter order is enc_1..enc_L, dec_1..dec_L, smrt_vae_encode writes the code
+                                          * [n][h_L] to mu_dev (logsig_dev may be NULL), smrt_vae_decode takes the code */
 } smrt_vae_cfg;
 
 /* Replaces graph construction + tf.global_variables_initializer (autoencoder.py:439-486, base.py:185-190).

@@ -37,7 +37,7 @@ class VaeCfg(C.Structure):
         ("n_latent", C.c_int32), ("activation", C.c_int32), ("optimizer", C.c_int32),
         ("learning_rate", C.c_float), ("l2_penalty", C.c_float), ("clip", C.c_int32),
         ("gclip_min", C.c_float), ("gclip_max", C.c_float), ("bce_lo", C.c_float), ("bce_hi", C.c_float),
-        ("dropout_keep", C.c_float), ("seed", C.c_uint64), ("max_batch", C.c_int32),
+        ("dropout_keep", C.c_float), ("seed", C.c_uint64), ("max_batch", C.c_int32), ("model", C.c_int32),
     ]
 
 
@@ -159,7 +159,7 @@ class VaeHandle(object):
     """Owns one ``smrt_vae*``.  Methods take/return numpy arrays or torch device tensors."""
 
     def __init__(self, n_features, hidden, n_latent, activation, optimizer, learning_rate, l2_penalty, clip,
-                 gclip_min, gclip_max, eps, dropout, seed, max_batch, device=0):
+                 gclip_min, gclip_max, eps, dropout, seed, max_batch, device=0, model="vae"):
         lib = load()
         torch = _torch()
         if len(hidden) > MAX_HIDDEN:
@@ -177,6 +177,9 @@ class VaeHandle(object):
         cfg.dropout_keep = float(dropout)
         cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         cfg.max_batch = int(max_batch)
+        cfg.model = {"vae": 0, "ae": 1}[model]
+        self.model = model
+        self.code_width = int(n_latent) if model == "vae" else int(hidden[-1])
         self.device = torch.device("cuda", int(device))
         self.n_features, self.n_latent, self.hidden = int(n_features), int(n_latent), list(hidden)
         self._h = C.c_void_p()
@@ -236,9 +239,13 @@ class VaeHandle(object):
 
     # -- training
     def _as_dev(self, X):
-        """numpy [n,d] or (tensor, ld) -> (tensor, ld) on this handle's device."""
+        """numpy [n,d], a contiguous fp32 device tensor [n, d % 4 == 0] or (tensor, ld) -> (tensor, ld) on this device."""
         if isinstance(X, tuple):
             return X
+        if hasattr(X, "data_ptr"):
+            if X.shape[1] % 4 == 0 and X.is_contiguous():
+                return X, X.shape[1]
+            X = X.cpu().numpy()
         return to_device_padded(X, self.device)
 
     def train_step(self, X, eps=None, want_grads=False):
@@ -340,7 +347,12 @@ class VaeHandle(object):
         torch = _torch()
         Xt, ldx = self._as_dev(X)
         n = Xt.shape[0]
-        mu = torch.empty((n, self.n_latent), dtype=torch.float32, device=self.device)
+        mu = torch.empty((n, self.code_width), dtype=torch.float32, device=self.device)
+        if self.model == "ae":                          # the code of the plain auto-encoder: one array
+            torch.cuda.synchronize(self.device)
+            if n:
+                _check(self._lib.smrt_vae_encode(self._live(), Xt.data_ptr(), ldx, n, mu.data_ptr(), None), "smrt_vae_encode")
+            return mu.cpu().numpy() if to_host else mu
         ls = torch.empty((n, self.n_latent), dtype=torch.float32, device=self.device)
         torch.cuda.synchronize(self.device)
         if n:

@@ -38,6 +38,8 @@ struct smrt_vae {
     hipStream_t stream = nullptr;        // stream in use (own_stream unless the caller lent one)
     hipStream_t own_stream = nullptr;
     int L = 0, NL = 0, Z = 0, D = 0;
+    bool ae = false;                     // plain auto-encoder (no latent heads, MSE loss)
+    int hl = 0, dec0 = 0, Zc = 0;        // index of the fused heads layer (-2: none), first decoder layer, code width
     LayerI lay[MAX_LAYERS];
     long P_int = 0, P_abi = 0;
     int maxld = 0;
@@ -124,8 +126,10 @@ struct ProfScope {
 // ------------------------------------------------------------------ layout helpers
 static void build_layers(smrt_vae* h) {
     const smrt_vae_cfg& c = h->cfg;
-    h->L = c.n_hidden_layers; h->Z = c.n_latent; h->D = c.n_features;
-    h->NL = 2 * h->L + 2;
+    h->ae = (c.model == SMRT_MODEL_AE);
+    h->L = c.n_hidden_layers; h->D = c.n_features;
+    h->Z = h->ae ? 1 : c.n_latent;
+    h->NL = h->ae ? 2 * h->L : 2 * h->L + 2;
     std::vector<int> w(1, c.n_features);
     for (int i = 0; i < h->L; ++i) w.push_back(c.hidden[i]);
     int li = 0; long off = 0, pabi = 0; int maxld = rup4(c.n_features);
@@ -136,12 +140,20 @@ static void build_layers(smrt_vae* h) {
         maxld = std::max(maxld, y.ld);
     };
     for (int i = 0; i < h->L; ++i) { add(w[i], w[i + 1], c.activation, 1); pabi += (long)w[i] * w[i + 1] + w[i + 1]; }
-    add(w[h->L], 2 * h->Z, c.activation, 0);          // fused heads: never regularised (layer.py:96)
-    pabi += 2 * ((long)w[h->L] * h->Z + h->Z);
-    add(h->Z, w[h->L], c.activation, 1); pabi += (long)h->Z * w[h->L] + w[h->L];
-    for (int i = h->L; i >= 1; --i) {
-        const int act = (i == 1) ? SMRT_ACT_SIGMOID : c.activation;       // layer.py:333-338
-        add(w[i], w[i - 1], act, 1); pabi += (long)w[i] * w[i - 1] + w[i - 1];
+    if (h->ae) {
+        // SymmetricalAutoEncoderTopography (layer.py:163-190): the decoder mirrors the encoder, every layer with
+        // the user's activation, every layer regularised
+        h->hl = -2; h->dec0 = h->L; h->Zc = w[h->L];
+        for (int i = h->L; i >= 1; --i) { add(w[i], w[i - 1], c.activation, 1); pabi += (long)w[i] * w[i - 1] + w[i - 1]; }
+    } else {
+        h->hl = h->L; h->dec0 = h->L + 1; h->Zc = h->Z;
+        add(w[h->L], 2 * h->Z, c.activation, 0);          // fused heads: never regularised (layer.py:96)
+        pabi += 2 * ((long)w[h->L] * h->Z + h->Z);
+        add(h->Z, w[h->L], c.activation, 1); pabi += (long)h->Z * w[h->L] + w[h->L];
+        for (int i = h->L; i >= 1; --i) {
+            const int act = (i == 1) ? SMRT_ACT_SIGMOID : c.activation;       // layer.py:333-338
+            add(w[i], w[i - 1], act, 1); pabi += (long)w[i] * w[i - 1] + w[i - 1];
+        }
     }
     h->P_int = off; h->P_abi = pabi; h->maxld = std::max(maxld, rup4(h->Z));
 }
@@ -158,6 +170,7 @@ static void convert(const smrt_vae* h, float* abi, float* internal, bool to_inte
             }
         o += (long)(y.fi + 1) * y.fo;
     };
+    if (h->ae) { for (int l = 0; l < h->NL; ++l) plain(h->lay[l]); return; }
     for (int l = 0; l < h->L; ++l) plain(h->lay[l]);
     {
         const LayerI& y = h->lay[h->L]; const int Z = h->Z;
@@ -180,7 +193,7 @@ static void fill_segs(const smrt_vae* h, OptSeg* seg) {
         const LayerI& y = h->lay[l];
         OptSeg& s = seg[l];
         s.start = y.off; s.w_count = (long)y.fi * y.ld; s.total = (long)(y.fi + 1) * y.ld;
-        s.ld = y.ld; s.fo = y.fo; s.l2 = y.l2; s.is_heads = (l == h->L);
+        s.ld = y.ld; s.fo = y.fo; s.l2 = y.l2; s.is_heads = (l == h->hl);
         s.abi_w_off = abi_w; s.Z = h->Z; s.hfi = y.fi;
         abi_w += (long)y.fi * y.fo;
     }
@@ -219,7 +232,7 @@ static void plan_fused(smrt_vae* h) {
     const char* e = std::getenv("SMRT_HIP_FUSED");
     const bool want = e ? std::atoi(e) != 0 : true;
     const int bytes = off * (int)sizeof(float);
-    h->fused = want && bytes <= 150 * 1024;
+    h->fused = want && bytes <= 150 * 1024 && !h->ae;
     if (h->fused && bytes > 48 * 1024 && fused_set_max_lds(bytes) != 0) { (void)hipGetLastError(); h->fused = false; }
 }
 
@@ -358,11 +371,12 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         { ProfScope ps(h, PK_DROPOUT); launch_dropout(s, d); } ++launches;
         Wuse = h->Wd;
     }
-    auto in_of = [&](int l) -> const float* { return l == 0 ? X : (l == L + 1 ? h->Zb : h->out[l - 1]); };
-    auto ldin_of = [&](int l) -> long { return l == 0 ? ldx : (l == L + 1 ? (long)rup4(Z) : (long)h->lay[l - 1].ld); };
+    const int HL = h->hl;               // fused latent heads layer (-2 for the plain auto-encoder: never matches)
+    auto in_of = [&](int l) -> const float* { return l == 0 ? X : (l == HL + 1 ? h->Zb : h->out[l - 1]); };
+    auto ldin_of = [&](int l) -> long { return l == 0 ? ldx : (l == HL + 1 ? (long)rup4(Z) : (long)h->lay[l - 1].ld); };
 
     int n_bce = 0;
-    int n_kl = reparam_blocks(rows, Z);
+    int n_kl = h->ae ? 0 : reparam_blocks(rows, Z);
     const bool fused_step = h->fused && mode == 0 && rows <= 512;      // two-kernel step on the transposed workspace
     if (fused_step) {
         if (h->has_drop) {           // the image follows the post-dropout weights of this step
@@ -454,7 +468,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
                 if (once <= 3) fprintf(stderr, "   whole workgroup incl. epilogue: %.2f us\n", (double)hb[3] * 0.01);
             }
 #endif
-            if (l == L) {
+            if (l == HL) {
                 ProfScope ps(h, PK_REPARAM);
                 launch_reparam(s, h->out[L], y.ld, eps_in, h->Zb, h->Eb, rup4(Z), rows, Z, h->cfg.seed, h->st,
                                row0_global, h->kl_p);
@@ -462,9 +476,11 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             }
         } else {
             a.C = h->dpre[l]; a.ldc = y.ld; a.aux = X; a.ldaux = ldx;
-            a.lo = h->cfg.bce_lo; a.hi = h->cfg.bce_hi; a.inv_batch = inv_batch; a.partials = h->bce_p;
+            a.lo = h->cfg.bce_lo; a.hi = h->cfg.bce_hi; a.partials = h->bce_p;
+            // the auto-encoder's loss is the mean over ALL B*D elements (autoencoder.py:260)
+            a.inv_batch = h->ae ? inv_batch / (float)h->D : inv_batch;
             n_bce = gemm_grid_blocks(GEMM_NN, a);
-            { ProfScope ps(h, PK_FWD_BCE); launch_gemm(s, GEMM_NN, EPI_BCE, a); } ++launches;
+            { ProfScope ps(h, PK_FWD_BCE); launch_gemm(s, GEMM_NN, h->ae ? EPI_MSE : EPI_BCE, a); } ++launches;
         }
     }
     // ---- backward through the activations
@@ -474,7 +490,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         a.A = h->dpre[l]; a.lda = y.ld; a.M = rows; a.K = y.fo;
         a.B = Wuse + y.off; a.ldb = y.ld; a.N = y.fi;
         a.Z = Z; a.inv_batch = inv_batch;
-        if (l == L + 1) {
+        if (l == HL + 1) {
             a.C = h->dpre[L]; a.ldc = h->lay[L].ld; a.aux = h->out[L]; a.ldaux = h->lay[L].ld;
             a.aux2 = h->Eb; a.ldaux2 = rup4(Z); a.act = h->lay[L].act;
             { ProfScope ps(h, PK_BWD_LATENT); launch_gemm(s, GEMM_NT, EPI_LATENT, a); }
@@ -545,7 +561,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         { ProfScope ps(h, PK_REDUCE); launch_reduce_slabs(s, h->G, splits, h->P_int, h->P_int, o.dp_out); } ++launches;
         FinalizeArgs f{};
         f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = nullptr; f.n_l2 = 0;
-        f.inv_batch = inv_batch; f.l2 = 0.f; f.loss_sum_out = o.dp_out + h->P_int; f.st = h->st; f.advance = 0;
+        f.inv_batch = h->ae ? inv_batch / (float)h->D : inv_batch; f.l2 = 0.f; f.loss_sum_out = o.dp_out + h->P_int; f.st = h->st; f.advance = 0;
         { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
         h->last_epoch_launches = launches;
         return 0;
@@ -562,7 +578,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
     h->img_valid = false;
     FinalizeArgs f{};
     f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p; f.n_l2 = h->n_l2;
-    f.inv_batch = inv_batch; f.l2 = p.l2; f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
+    f.inv_batch = h->ae ? inv_batch / (float)h->D : inv_batch; f.l2 = p.l2; f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
     f.st = h->st; f.advance = 1;
     { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
     h->last_epoch_launches = launches;
@@ -577,7 +593,9 @@ const char* smrt_version(void) { return "smrt-hip 0.1 (gfx950)"; }
 
 int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
     if (!cfg || !out) return fail(-1, "smrt_vae_create: null argument");
-    if (cfg->n_features < 1 || cfg->n_latent < 1) return fail(-1, "smrt_vae_create: n_features and n_latent must be >= 1");
+    if (cfg->model != SMRT_MODEL_VAE && cfg->model != SMRT_MODEL_AE) return fail(-1, "smrt_vae_create: bad model id");
+    if (cfg->n_features < 1 || (cfg->n_latent < 1 && cfg->model == SMRT_MODEL_VAE))
+        return fail(-1, "smrt_vae_create: n_features and n_latent must be >= 1");
     if (cfg->n_hidden_layers < 1 || cfg->n_hidden_layers > SMRT_MAX_HIDDEN)
         return fail(-1, "smrt_vae_create: n_hidden_layers must be in 1..SMRT_MAX_HIDDEN");
     for (int i = 0; i < cfg->n_hidden_layers; ++i)
@@ -974,7 +992,7 @@ int smrt_vae_profile_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_
 static const long INFER_CHUNK = 32768;
 
 int smrt_vae_encode(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n, float* mu_dev, float* logsig_dev) {
-    if (!h || !mu_dev || !logsig_dev) return fail(-1, "smrt_vae_encode: null argument");
+    if (!h || !mu_dev || (!logsig_dev && !h->ae)) return fail(-1, "smrt_vae_encode: null argument");
     if (n < 0) return fail(-1, "smrt_vae_encode: n must be >= 0");
     if (n == 0) return 0;
     TRY(check_mat(X_dev, ldx, h->D, "smrt_vae_encode: X"));
@@ -984,15 +1002,19 @@ int smrt_vae_encode(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n, flo
     for (long r0 = 0; r0 < n; r0 += chunk) {
         const int rows = (int)std::min<long>(chunk, n - r0);
         const float* in = X_dev + r0 * ldx; long ldin = ldx;
-        for (int l = 0; l <= h->L; ++l) {
+        const int last = h->ae ? h->L - 1 : h->L;
+        for (int l = 0; l <= last; ++l) {
             const LayerI& y = h->lay[l];
             GemmArgs a{};
             a.A = in; a.lda = ldin; a.B = h->W + y.off; a.ldb = y.ld; a.bias = h->W + y.off + (long)y.fi * y.ld;
             a.M = rows; a.N = y.fo; a.K = y.fi; a.act = y.act; a.Z = h->Z;
-            if (l < h->L) {
+            if (l < last) {
                 a.C = h->ibuf[l & 1]; a.ldc = y.ld;
                 launch_gemm(h->stream, GEMM_NN, EPI_BIAS_ACT, a);
                 in = a.C; ldin = y.ld;
+            } else if (h->ae) {
+                a.C = mu_dev + r0 * h->Zc; a.ldc = h->Zc;              // the code, [n][h_L] contiguous
+                launch_gemm(h->stream, GEMM_NN, EPI_BIAS_ACT, a);
             } else {
                 a.C = mu_dev + r0 * h->Z; a.out2 = logsig_dev + r0 * h->Z;
                 launch_gemm(h->stream, GEMM_NN, EPI_HEADS_SPLIT, a);
@@ -1006,7 +1028,7 @@ int smrt_vae_encode(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n, flo
 
 static int decode_chunk(smrt_vae* h, const float* Zin, long ldz, int rows, float* out, long ldo) {
     const float* in = Zin; long ldin = ldz;
-    for (int l = h->L + 1; l < h->NL; ++l) {
+    for (int l = h->dec0; l < h->NL; ++l) {
         const LayerI& y = h->lay[l];
         GemmArgs a{};
         a.A = in; a.lda = ldin; a.B = h->W + y.off; a.ldb = y.ld; a.bias = h->W + y.off + (long)y.fi * y.ld;
@@ -1023,7 +1045,7 @@ int smrt_vae_decode(smrt_vae* h, const float* Z_dev, int64_t ldz, int64_t n, flo
     if (!h || !out_dev) return fail(-1, "smrt_vae_decode: null argument");
     if (n < 0) return fail(-1, "smrt_vae_decode: n must be >= 0");
     if (n == 0) return 0;
-    TRY(check_mat(Z_dev, ldz, h->Z, "smrt_vae_decode: Z"));
+    TRY(check_mat(Z_dev, ldz, h->Zc, "smrt_vae_decode: Z"));
     if (ldo < h->D) return fail(-1, "smrt_vae_decode: ldo must be >= n_features");
     HIPC(hipSetDevice(h->device));
     const long chunk = std::min<long>(n, INFER_CHUNK);
@@ -1042,6 +1064,7 @@ int smrt_vae_generate(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc,
     if (!h || !out_dev) return fail(-1, "smrt_vae_generate: null argument");
     if (n < 0) return fail(-1, "smrt_vae_generate: n must be >= 0");
     if (n == 0) return 0;
+    if (h->ae) return fail(-1, "smrt_vae_generate: a plain auto-encoder has no generative prior");
     if (ldo < h->D) return fail(-1, "smrt_vae_generate: ldo must be >= n_features");
     HIPC(hipSetDevice(h->device));
     const long chunk = std::min<long>(n, INFER_CHUNK);

@@ -95,6 +95,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
         });
         const float tot = block_sum_256(lsum, red);
         if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    } else if constexpr (EPI == EPI_MSE) {
+        // plain auto-encoder output layer: y = act(.), squared error summed into a block partial and
+        // dL/dpre = 2 (y - x) / (B D) * act'(y) emitted directly (autoencoder.py:260); a.inv_batch = 1 / (B D)
+        float lsum = 0.f;
+        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+            if (row < a.M && col < a.N) {
+                const float y = act_fwd(a.act, v + a.bias[col]);
+                const float d = y - a.aux[(long)row * a.ldaux + col];
+                lsum += d * d;
+                a.C[(long)row * a.ldc + col] = act_bwd(a.act, y, 2.0f * d * a.inv_batch);
+            }
+        });
+        const float tot = block_sum_256(lsum, red);
+        if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
     } else if constexpr (EPI == EPI_ACTGRAD) {
         // dPre_prev = (dPre . W^T) * act'(y_prev)
         if (m0 + BM <= a.M && n0 + BN <= a.N) {
@@ -156,6 +170,7 @@ void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a) {
     if (kind == GEMM_NN) {
         if (epi == EPI_BIAS_ACT)         launch_gemm_t<INNER, OUTER, EPI_BIAS_ACT>(s, a);
         else if (epi == EPI_BCE)         launch_gemm_t<INNER, OUTER, EPI_BCE>(s, a);
+        else if (epi == EPI_MSE)         launch_gemm_t<INNER, OUTER, EPI_MSE>(s, a);
         else                             launch_gemm_t<INNER, OUTER, EPI_HEADS_SPLIT>(s, a);
     } else {
         if (epi == EPI_ACTGRAD)          launch_gemm_t<INNER, INNER, EPI_ACTGRAD>(s, a);

@@ -25,7 +25,7 @@ struct DevState {
     uint32_t pad;
 };
 
-enum Epi : int { EPI_BIAS_ACT = 0, EPI_BCE = 1, EPI_HEADS_SPLIT = 2, EPI_ACTGRAD = 3, EPI_LATENT = 4 };
+enum Epi : int { EPI_BIAS_ACT = 0, EPI_BCE = 1, EPI_HEADS_SPLIT = 2, EPI_ACTGRAD = 3, EPI_LATENT = 4, EPI_MSE = 5 };
 enum GemmKind : int { GEMM_NN = 0, GEMM_NT = 1 };
 
 struct GemmArgs {
