@@ -268,15 +268,23 @@ static int arena_alloc(Arena& a, size_t bytes) {
 static int dw_tiles(const smrt_vae* h, int t) {
     int tot = 0;
     for (int l = 0; l < h->NL; ++l)
-        tot += ((h->lay[l].fi + 1 + t - 1) / t) * ((h->lay[l].fo + t - 1) / t);
+        tot += ((h->lay[l].fi + t - 1) / t) * ((h->lay[l].fo + t - 1) / t);     // bias row: column sums, no tile
     return tot;
 }
 static bool dw_big(const smrt_vae* h, int rows) { return rows >= 2048 && dw_tiles(h, 128) >= 48; }
+// Split-K factor of the weight-gradient launch: tiles x splits workgroups should fill a whole number of "rounds" of
+// the chip (256 CUs x 2 resident workgroups): 440 tiles x 3 splits is 2.6 rounds and runs as long as 3.
 static int choose_splits(const smrt_vae* h, int rows) {
     const int T = dw_tiles(h, dw_big(h, rows) ? 128 : 64);
-    int s = (1024 + T - 1) / T;
-    s = std::min(s, (rows + 127) / 128);
-    return std::max(1, std::min(s, 32));
+    const int slots = 512;
+    const int smax = std::max(1, std::min(32, rows / 512));          // keep >= 512 rows (16 K-tiles) per split
+    int best = 1; double best_eff = 0.0;
+    for (int s = 1; s <= smax; ++s) {
+        const double r = (double)T * s / slots;
+        const double eff = r / std::ceil(r);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }    // smaller split (less slab traffic) on near ties
+    }
+    return best;
 }
 
 static int ensure_train(smrt_vae* h, int rows) {
@@ -550,7 +558,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             q.A = in_of(l); q.lda = ldin_of(l); q.B = h->dpre[l]; q.ldb = y.ld;
             q.C = h->G + y.off; q.ldc = y.ld; q.fi = y.fi; q.fo = y.fo;
             q.tiles_n = (y.fo + t - 1) / t; q.tile_begin = tb;
-            tb += ((y.fi + 1 + t - 1) / t) * q.tiles_n;
+            tb += ((y.fi + t - 1) / t) * q.tiles_n;
         }
         d.n_layers = NL; d.total_tiles = tb; d.rows = rows; d.splits = splits;
         d.k_per_split = (((rows + splits - 1) / splits) + 31) & ~31;

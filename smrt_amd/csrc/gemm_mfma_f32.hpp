@@ -56,27 +56,25 @@ struct Stage {
             }
             return;
         }
+        // Edge tiles: branch-free.  Every lane loads 16 bytes from a CLAMPED in-bounds address (row clamped to the last
+        // real row, column quad clamped to the last quad of the leading dimension) and out-of-range components are
+        // then replaced by 0 (or by 1 for the virtual ones index) with selects.  The element-wise branched form costs
+        // hundreds of scalar/branch instructions per K-tile on every edge workgroup (a quarter of the tiles of a
+        // 450-wide layer).
+        const int ldq = (int)ld - 4;
         if constexpr (LAY == INNER) {
             const int row = tid >> 3, kq = (tid & 7) * 4;
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
                 const int mn = mn0 + row + 32 * p, k = k0 + kq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mn < MN_data && k < K) {
-                    const float* ptr = g + (long)mn * ld + k;
-                    if (k + 3 < K) {
-                        v = *reinterpret_cast<const float4*>(ptr);
-                    } else {
-                        v.x = ptr[0];
-                        if (k + 1 < K) v.y = ptr[1];
-                        if (k + 2 < K) v.z = ptr[2];
-                    }
-                } else if (ONES && mn == MN_data && k < K) {
-                    v.x = 1.f;
-                    if (k + 1 < K) v.y = 1.f;
-                    if (k + 2 < K) v.z = 1.f;
-                    if (k + 3 < K) v.w = 1.f;
-                }
+                const float4 t = *reinterpret_cast<const float4*>(g + (long)min(mn, MN_data - 1) * ld + min(k, ldq));
+                const bool in = mn < MN_data;
+                const float one = (ONES && mn == MN_data) ? 1.f : 0.f;
+                float4 v;
+                v.x = (k     < K) ? (in ? t.x : one) : 0.f;
+                v.y = (k + 1 < K) ? (in ? t.y : one) : 0.f;
+                v.z = (k + 2 < K) ? (in ? t.z : one) : 0.f;
+                v.w = (k + 3 < K) ? (in ? t.w : one) : 0.f;
                 r[p] = v;
             }
         } else {
@@ -85,26 +83,23 @@ struct Stage {
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
                 const int k = k0 + krow + RPP * p, mn = mn0 + mq;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K) {
-                    const float* ptr = g + (long)k * ld + mn;
-                    if (mn + 3 < MN_data) {
-                        v = *reinterpret_cast<const float4*>(ptr);
-                    } else {
-                        if (mn < MN_data) v.x = ptr[0];
-                        if (mn + 1 < MN_data) v.y = ptr[1];
-                        if (mn + 2 < MN_data) v.z = ptr[2];
-                        if (ONES) {
-                            if (mn == MN_data) v.x = 1.f;
-                            if (mn + 1 == MN_data) v.y = 1.f;
-                            if (mn + 2 == MN_data) v.z = 1.f;
-                            if (mn + 3 == MN_data) v.w = 1.f;
-                        }
-                    }
-                }
+                const float4 t = *reinterpret_cast<const float4*>(g + (long)min(k, K - 1) * ld + min(mn, ldq));
+                const bool kin = k < K;
+                float4 v;
+                v.x = kin ? (mn     < MN_data ? t.x : ((ONES && mn     == MN_data) ? 1.f : 0.f)) : 0.f;
+                v.y = kin ? (mn + 1 < MN_data ? t.y : ((ONES && mn + 1 == MN_data) ? 1.f : 0.f)) : 0.f;
+                v.z = kin ? (mn + 2 < MN_data ? t.z : ((ONES && mn + 2 == MN_data) ? 1.f : 0.f)) : 0.f;
+                v.w = kin ? (mn + 3 < MN_data ? t.w : ((ONES && mn + 3 == MN_data) ? 1.f : 0.f)) : 0.f;
                 r[p] = v;
             }
         }
+    }
+
+    // Add this thread's staged values into its running per-column sums (OUTER layout: each float4 is 4 consecutive
+    // mn entries of one k row, the same 4 columns in every pass).  Out-of-range entries were staged as zeros.
+    __device__ __forceinline__ void add_to(float4& cs) const {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) { cs.x += r[p].x; cs.y += r[p].y; cs.z += r[p].z; cs.w += r[p].w; }
     }
 
     __device__ __forceinline__ void store(float* lds, int tid) const {
@@ -138,11 +133,13 @@ __device__ __forceinline__ void read_frag(const float* lds, int base_mn, int kb,
 
 // ------------------------------------------------------------------ block-tile main loop
 // Accumulates A[m0.., kbeg..kend) * B[kbeg..kend), n0..) into acc[WM][WN].
+// bsum (optional): per-thread running sums over k of the B values this thread stages (Stage::add_to) -- the
+// weight-gradient kernel turns them into the bias gradient (column sums of dPre) without an extra row of MFMA tiles.
 template <int ALAY, int BLAY, int WM, int WN, bool A_ONES>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda, int M_data,
                                           const float* __restrict__ B, long ldb, int N_data,
                                           int m0, int n0, int kbeg, int kend,
-                                          float* ldsA, float* ldsB, f32x16 (&acc)[WM][WN]) {
+                                          float* ldsA, float* ldsB, f32x16 (&acc)[WM][WN], float4* bsum = nullptr) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -167,6 +164,7 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda,
     }
     sa.store(ldsA, tid);
     sb.store(ldsB, tid);
+    if (bsum) sb.add_to(*bsum);
     __syncthreads();
 
     // ldsA / ldsB each hold TWO tile images: K-tile t is computed from image t & 1 while the registers staged for
@@ -213,6 +211,7 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda,
         if (more) {
             sa.store(ldsA + (buf ^ 1) * SZA, tid);
             sb.store(ldsB + (buf ^ 1) * SZB, tid);
+            if (bsum) sb.add_to(*bsum);
             __syncthreads();
         }
     }

@@ -16,7 +16,7 @@ namespace smrt {
 // Dense-layer GEMM with fused epilogues
 // =====================================================================================
 template <int ALAY, int BLAY, int WM, int WN, int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a) {   // 2 waves per SIMD: <= 256 VGPR + AGPR
     constexpr int BM = 64 * WM, BN = 64 * WN;
     __shared__ __align__(16) float ldsA[2 * lds_floats<ALAY, BM>()];      // two tile images each (gemm_tile)
     __shared__ __align__(16) float ldsB[2 * lds_floats<BLAY, BN>()];
@@ -78,21 +78,49 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
         // last decoder layer: p = sigmoid(.), clipped Bernoulli NLL summed into a block partial, and
         // dL/dpre emitted directly.                     layer.py:333-338, _ae_utils.py:31-32
         float lsum = 0.f;
-        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-            if (row < a.M && col < a.N) {
-                const float p = 1.0f / (1.0f + expf(-(v + a.bias[col])));
-                const float x = a.aux[(long)row * a.ldaux + col];
-                const float pl = fmaxf(p, a.lo);
-                const float pc = fminf(pl, a.hi);
-                const float om = 1.0f - pc;
-                lsum -= x * logf(pc) + (1.0f - x) * logf(om);
-                // TF clip_by_value gradient gate: Maximum passes where p >= lo, Minimum where max(p,lo) <= hi
-                const bool pass = (p >= a.lo) && (pl <= a.hi);
-                const float dp = pass ? -(x / pc - (1.0f - x) / om) * a.inv_batch : 0.0f;
-                a.C[(long)row * a.ldc + col] = dp * p * (1.0f - p);
-                if (a.out2) a.out2[(long)row * a.ldout2 + col] = p;
-            }
-        });
+        auto bce_elem = [&](float v, float x, float b, float& dpre) {
+            const float p = fast_sigmoid(v + b);
+            const float pl = fmaxf(p, a.lo);
+            const float pc = fminf(pl, a.hi);
+            const float om = 1.0f - pc;
+            lsum -= x * __logf(pc) + (1.0f - x) * __logf(om);
+            // TF clip_by_value gradient gate: Maximum passes where p >= lo, Minimum where max(p,lo) <= hi
+            const bool pass = (p >= a.lo) && (pl <= a.hi);
+            const float dp = pass ? -(x * __builtin_amdgcn_rcpf(pc) - (1.0f - x) * __builtin_amdgcn_rcpf(om)) * a.inv_batch : 0.0f;
+            dpre = dp * p * (1.0f - p);
+            return p;
+        };
+        if (m0 + BM <= a.M && n0 + BN <= a.N && !a.out2) {
+            // interior tiles: bias once per column, the 16 targets of a sub-tile fetched in one batch (see ACTGRAD)
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int col = n0 + wc * 32 * WN + j * 32 + r;
+                    const int rowb = m0 + wr * 32 * WM + i * 32 + 4 * h;
+                    const float b = a.bias[col];
+                    float x[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) x[e] = a.aux[(long)(rowb + (e & 3) + 8 * (e >> 2)) * a.ldaux + col];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float d;
+                        bce_elem(acc[i][j][e], x[e], b, d);
+                        a.C[(long)(rowb + (e & 3) + 8 * (e >> 2)) * a.ldc + col] = d;
+                    }
+                }
+        } else {
+            for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+                if (row < a.M && col < a.N) {
+                    float d;
+                    const float p = bce_elem(v, a.aux[(long)row * a.ldaux + col], a.bias[col], d);
+                    a.C[(long)row * a.ldc + col] = d;
+                    if (a.out2) a.out2[(long)row * a.ldout2 + col] = p;
+                }
+            });
+        }
         const float tot = block_sum_256(lsum, red);
         if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
     } else if constexpr (EPI == EPI_MSE) {
@@ -112,9 +140,25 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs a) {
     } else if constexpr (EPI == EPI_ACTGRAD) {
         // dPre_prev = (dPre . W^T) * act'(y_prev)
         if (m0 + BM <= a.M && n0 + BN <= a.N) {
-            for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-                a.C[(long)row * a.ldc + col] = act_bwd(a.act, a.aux[(long)row * a.ldaux + col], v);
-            });
+            // Interior tiles: the 16 y_prev values of a 32x32 sub-tile are fetched in one batch, then combined and
+            // stored.  Element by element, every load would queue behind the previous element's store (C may alias
+            // aux as far as the compiler knows): 64 dependent memory round trips per lane.
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int col = n0 + wc * 32 * WN + j * 32 + r;
+                    const int rowb = m0 + wr * 32 * WM + i * 32 + 4 * h;
+                    float y[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        y[e] = a.aux[(long)(rowb + (e & 3) + 8 * (e >> 2)) * a.ldaux + col];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        a.C[(long)(rowb + (e & 3) + 8 * (e >> 2)) * a.ldc + col] = act_bwd(a.act, y[e], acc[i][j][e]);
+                }
         } else {
             for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
                 if (row < a.M && col < a.N)
@@ -182,7 +226,7 @@ void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a) {
 // Weight + bias gradients of every layer in one launch:  [X | 1]^T . dPre   (split-K into slabs)
 // =====================================================================================
 template <int WM, int WN>
-__global__ __launch_bounds__(GEMM_THREADS) void dw_kernel(const DwArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS, 2) void dw_kernel(const DwArgs a) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     __shared__ __align__(16) float ldsA[2 * lds_floats<OUTER, BM>()];
     __shared__ __align__(16) float ldsB[2 * lds_floats<OUTER, BN>()];
@@ -198,12 +242,33 @@ __global__ __launch_bounds__(GEMM_THREADS) void dw_kernel(const DwArgs a) {
     const int kend = min(a.rows, kbeg + a.k_per_split);
 
     f32x16 acc[WM][WN];
-    gemm_tile<OUTER, OUTER, WM, WN, true>(L.A, L.lda, L.fi, L.B, L.ldb, L.fo, m0, n0, kbeg, kend, ldsA, ldsB, acc);
+    // The bias gradient is the column sum of dPre: the workgroups of the first row of tiles add up the B values they
+    // stage anyway (16 VALU adds per K-tile), instead of a virtual ones row that costs a whole extra row of MFMA tiles
+    // whenever fan_in is a multiple of the tile height.
+    const bool want_db = (m0 == 0);
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    gemm_tile<OUTER, OUTER, WM, WN, false>(L.A, L.lda, L.fi, L.B, L.ldb, L.fo, m0, n0, kbeg, kend, ldsA, ldsB, acc,
+                                           want_db ? &cs : nullptr);
 
     float* C = L.C + (long)blockIdx.y * a.slab_stride;
     for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-        if (row <= L.fi && col < L.fo) C[(long)row * L.ldc + col] = v;     // row == fi is the bias gradient
+        if (row < L.fi && col < L.fo) C[(long)row * L.ldc + col] = v;
     });
+    if (want_db) {
+        // thread t staged columns 4*(t % F4).. of k rows t / F4 (+ multiples of RPP): reduce the RPP partials per column
+        constexpr int F4 = BN / 4, RPP = GEMM_THREADS / F4;
+        __syncthreads();                                   // every wave is done reading the tile images
+        float* red = ldsB;                                 // [RPP][BN]
+        *reinterpret_cast<float4*>(red + (threadIdx.x / F4) * BN + (threadIdx.x % F4) * 4) = cs;
+        __syncthreads();
+        if (threadIdx.x < BN) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < RPP; ++i) t += red[i * BN + threadIdx.x];
+            const int col = n0 + threadIdx.x;
+            if (col < L.fo) C[(long)L.fi * L.ldc + col] = t;        // row fan_in of the augmented matrix = bias
+        }
+    }
 }
 
 void launch_dw(hipStream_t s, const DwArgs& a, bool big) {
