@@ -294,7 +294,9 @@ static int ensure_train(smrt_vae* h, int rows) {
     HIPC(hipStreamSynchronize(h->stream));
     const int nsplit = std::max(splits, h->g_splits_cap);
     const int cap = (std::max(std::max(rows, h->cap_rows), (int)h->cfg.max_batch) + 15) & ~15;   // fused kernels store whole 16-row tiles
-    const int nb = std::max(((cap + 63) / 64) * ((h->D + 63) / 64), (cap + 15) / 16);
+    // loss partials: one per workgroup of the output-layer GEMM (64x64 tiles, or 32x32 in the small-batch kernels)
+    const int nb = std::max(std::max(((cap + 63) / 64) * ((h->D + 63) / 64), (cap + 15) / 16),
+                            ((std::min(cap, SMALL_M_MAX) + 31) / 32) * ((h->D + 31) / 32));
     auto layout = [&](Arena& a) {
         a.off = 0;
         carve(a, &h->G, (size_t)nsplit * h->P_int);
@@ -546,11 +548,12 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         return 0;
     }
     // ---- all weight/bias gradients in one launch
-    const int splits = std::min(choose_splits(h, rows), h->g_splits_cap);
+    const bool small = rows <= SMALL_M_MAX;              // register-fed 32x32 tiles, one slab, bias row via a ones index
+    const int splits = small ? 1 : std::min(choose_splits(h, rows), h->g_splits_cap);
     const bool big = dw_big(h, rows);
     {
         DwArgs d{};
-        const int t = big ? 128 : 64;
+        const int t = small ? 32 : (big ? 128 : 64);
         int tb = 0;
         for (int l = 0; l < NL; ++l) {
             const LayerI& y = h->lay[l];
@@ -558,12 +561,12 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             q.A = in_of(l); q.lda = ldin_of(l); q.B = h->dpre[l]; q.ldb = y.ld;
             q.C = h->G + y.off; q.ldc = y.ld; q.fi = y.fi; q.fo = y.fo;
             q.tiles_n = (y.fo + t - 1) / t; q.tile_begin = tb;
-            tb += ((y.fi + t - 1) / t) * q.tiles_n;
+            tb += ((y.fi + (small ? 1 : 0) + t - 1) / t) * q.tiles_n;
         }
         d.n_layers = NL; d.total_tiles = tb; d.rows = rows; d.splits = splits;
         d.k_per_split = (((rows + splits - 1) / splits) + 31) & ~31;
         d.slab_stride = h->P_int;
-        { ProfScope ps(h, PK_DW); launch_dw(s, d, big); } ++launches;
+        { ProfScope ps(h, PK_DW); if (small) launch_small_dw(s, d); else launch_dw(s, d, big); } ++launches;
     }
     if (mode == 1) {
         { ProfScope ps(h, PK_REDUCE); launch_reduce_slabs(s, h->G, splits, h->P_int, h->P_int, o.dp_out); } ++launches;

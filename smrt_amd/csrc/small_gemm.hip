@@ -1,0 +1,249 @@
+// Dense-layer GEMMs for SMALL mini-batches (M = rows <= SMALL_M_MAX), e.g. the reference's own configuration:
+// 784-450-(10,10)-450-784 at batch 128 / 256 (smrt/balance/tests/test_smrt.py:17-21).
+//
+// At these sizes the LDS-tiled kernel (gemm_mfma_f32.hpp) is latency-bound twice over: 256 x 450 outputs are 32 of
+// its 64x64 tiles (32 of 256 CUs busy), and each workgroup walks K = 784 as 25 dependent
+// global-load -> LDS -> barrier -> MFMA rounds of ~1 us.  Here instead
+//   * a workgroup owns ONE 32x32 output tile (120 workgroups for 256 x 450) and its four waves split K between them:
+//     wave w takes the 8-wide k-blocks with index = w (mod 4), so the dependent MFMA chain is 4x shorter;
+//   * each wave loads its operand fragments straight from global memory into registers in MFMA layout -- no LDS
+//     staging, no barrier in the main loop -- eight k-blocks (64 registers) per batch, the next batch requested
+//     before the current one is multiplied;
+//   * the four partial tiles meet in LDS once, and all 256 threads run the fused epilogue on 4 outputs each with
+//     16-byte stores.
+//
+// MFMA v_mfma_f32_32x32x2_f32 maps: lane l: r = l & 31, h = l >> 5; A operand A[m = r][k = h], B operand B[k = h][n = r];
+// C/D reg i: row = (i & 3) + 8 * (i >> 2) + 4 * h, col = r.  Inside an 8-wide k-block lane half h takes k = 4 h + s at step s
+// for BOTH operands (the MFMA sums over k), so a k-contiguous operand is one 16-byte load per k-block.
+//
+// Reference arithmetic: as vae_kernels.hip (layer.py:365-368, _ae_utils.py:15-49, base.py:127-149).
+#include "vae_kernels.hpp"
+#include "device_utils.hpp"
+#include "gemm_mfma_f32.hpp"
+
+namespace smrt {
+
+constexpr int ST = 32;                 // output tile edge
+constexpr int SG = 8;                  // k-blocks per wave per batch (8 x 8 = 64 k)
+constexpr int SRED = 33;               // LDS row stride of a partial tile
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// The four k-step values of one 8-wide k-block for this lane (k = kb + 4 h + s, s = 0..3), zero (or one, for the
+// virtual ones index of the bias gradient) outside the matrix.  Addresses are clamped in-bounds, values selected.
+template <int LAY, bool ONES>
+__device__ __forceinline__ f32x4v load_kblock(const float* __restrict__ g, long ld, int mn, int MN_data, int kb4, int K) {
+    f32x4v v;
+    const bool in = mn < MN_data;
+    const float fill = (ONES && mn == MN_data) ? 1.f : 0.f;
+    if constexpr (LAY == INNER) {       // [mn][k], k contiguous: one 16-byte load
+        const f32x4v t = *reinterpret_cast<const f32x4v*>(g + (long)min(mn, MN_data - 1) * ld + min(kb4, (int)ld - 4));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = (kb4 + s < K) ? (in ? t[s] : fill) : 0.f;
+    } else {                            // [k][mn], mn contiguous: four 4-byte loads, each 128 B contiguous per half-wave
+        const float* p = g + min(mn, MN_data - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float t = p[(long)min(kb4 + s, K - 1) * ld];
+            v[s] = (kb4 + s < K) ? (in ? t : fill) : 0.f;
+        }
+    }
+    return v;
+}
+
+// One 32x32 tile of A.B over k in [0, K): returns this thread's four reduced outputs (row = tid >> 3, columns
+// 4 * (tid & 7) .. + 3 of the tile).  `red` = 4 * 32 * SRED floats of LDS.
+template <int ALAY, int BLAY, bool A_ONES>
+__device__ __forceinline__ f32x4v small_tile(const float* __restrict__ A, long lda, int M_data,
+                                             const float* __restrict__ B, long ldb, int N_data,
+                                             int m0, int n0, int K, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int nkb = (K + 7) >> 3;                       // 8-wide k-blocks in all; this wave takes wave, wave + 4, ...
+    const int mine = (nkb - wave + 3) >> 2;             // how many of them are this wave's (may be 0)
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    f32x4v fa[SG], fb[SG], na[SG], nb[SG];
+    auto fetch = [&](int first, f32x4v (&xa)[SG], f32x4v (&xb)[SG]) {
+#pragma unroll
+        for (int j = 0; j < SG; ++j) {
+            // blocks past the end read a clamped address and select zeros (kb4 >= K)
+            const int kb4 = ((first + j) * 4 + wave) * 8 + 4 * h;
+            xa[j] = load_kblock<ALAY, A_ONES>(A, lda, m0 + r, M_data, kb4, K);
+            xb[j] = load_kblock<BLAY, false>(B, ldb, n0 + r, N_data, kb4, K);
+        }
+    };
+    if (mine > 0) fetch(0, fa, fb);
+#pragma unroll 1
+    for (int i = 0; i < mine; i += SG) {
+        const bool more = i + SG < mine;
+        if (more) fetch(i + SG, na, nb);
+        asm volatile("" ::: "memory");                   // next batch is requested before this one is multiplied
+        __builtin_amdgcn_sched_barrier(0);
+        const int cnt = min(SG, mine - i);
+#pragma unroll
+        for (int j = 0; j < SG; ++j) {
+            if (j < cnt) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j][s], fb[j][s], acc, 0, 0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < SG; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
+        }
+    }
+    // the four waves' partial tiles meet in LDS
+    float* mine_red = red + wave * (ST * SRED);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mine_red[((e & 3) + 8 * (e >> 2) + 4 * h) * SRED + r] = acc[e];
+    __syncthreads();
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
+    f32x4v out;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float* p = red + row * SRED + c4 + c;
+        out[c] = (p[0] + p[ST * SRED]) + (p[2 * ST * SRED] + p[3 * ST * SRED]);
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------ dense layer forward / backward
+template <int ALAY, int BLAY, int EPI>
+__global__ __launch_bounds__(256, 2) void small_gemm_kernel(const GemmArgs a) {
+    __shared__ float red[4 * ST * SRED];
+    __shared__ float sred[4];
+    const int m0 = blockIdx.y * ST, n0 = blockIdx.x * ST;
+    const f32x4v v = small_tile<ALAY, BLAY, false>(a.A, a.lda, a.M, a.B, a.ldb, a.N, m0, n0, a.K, red);
+    const int row = m0 + (threadIdx.x >> 3), col0 = n0 + (threadIdx.x & 7) * 4;
+    const bool rin = row < a.M;
+    float lsum = 0.f;
+    float o[4], o2[4];
+    bool cin[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { cin[c] = rin && (col0 + c) < a.N; o[c] = 0.f; o2[c] = 0.f; }
+
+    if constexpr (EPI == EPI_BIAS_ACT || EPI == EPI_HEADS_SPLIT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (cin[c]) o[c] = act_fwd(a.act, v[c] + a.bias[col0 + c]);      // layer.py:368
+    } else if constexpr (EPI == EPI_BCE) {
+        // sigmoid output + clipped Bernoulli NLL + dL/dpre (layer.py:333-338, _ae_utils.py:31-32)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (cin[c]) {
+            const float p = fast_sigmoid(v[c] + a.bias[col0 + c]);
+            const float x = a.aux[(long)row * a.ldaux + col0 + c];
+            const float pl = fmaxf(p, a.lo), pc = fminf(pl, a.hi), om = 1.0f - pc;
+            lsum -= x * __logf(pc) + (1.0f - x) * __logf(om);
+            const bool pass = (p >= a.lo) && (pl <= a.hi);
+            const float dp = pass ? -(x * __builtin_amdgcn_rcpf(pc) - (1.0f - x) * __builtin_amdgcn_rcpf(om)) * a.inv_batch : 0.0f;
+            o[c] = dp * p * (1.0f - p);
+            o2[c] = p;
+        }
+    } else if constexpr (EPI == EPI_MSE) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (cin[c]) {
+            const float y = act_fwd(a.act, v[c] + a.bias[col0 + c]);
+            const float d = y - a.aux[(long)row * a.ldaux + col0 + c];
+            lsum += d * d;
+            o[c] = act_bwd(a.act, y, 2.0f * d * a.inv_batch);
+        }
+    } else if constexpr (EPI == EPI_ACTGRAD) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (cin[c]) o[c] = act_bwd(a.act, a.aux[(long)row * a.ldaux + col0 + c], v[c]);
+    } else if constexpr (EPI == EPI_LATENT) {
+        // v = dL/dz -> both heads: dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B   (layer.py:279, _ae_utils.py:49)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (cin[c]) {
+            const int col = col0 + c;
+            const float mu = a.aux[(long)row * a.ldaux + col];
+            const float ls = a.aux[(long)row * a.ldaux + a.Z + col];
+            const float e = a.aux2[(long)row * a.ldaux2 + col];
+            const float el = expf(ls);
+            o[c] = act_bwd(a.act, mu, v[c] + mu * a.inv_batch);
+            o2[c] = act_bwd(a.act, ls, v[c] * e * el + (expf(2.0f * ls) - 1.0f) * a.inv_batch);
+        }
+    }
+
+    // ---- stores: 16 bytes per lane where the four columns are real and the destination quad is aligned
+    if constexpr (EPI == EPI_HEADS_SPLIT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) if (cin[c]) {
+            const int col = col0 + c;
+            if (col < a.Z) a.C[(long)row * a.Z + col] = o[c];
+            else           a.out2[(long)row * a.Z + (col - a.Z)] = o[c];
+        }
+    } else {
+        float* dst = a.C + (long)row * a.ldc + col0;
+        if (cin[3] && ((a.ldc & 3) == 0)) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (cin[c]) dst[c] = o[c];
+        }
+        if constexpr (EPI == EPI_LATENT) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (cin[c]) a.C[(long)row * a.ldc + a.Z + col0 + c] = o2[c];
+        }
+        if constexpr (EPI == EPI_BCE) {
+            if (a.out2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (cin[c]) a.out2[(long)row * a.ldout2 + col0 + c] = o2[c];
+            }
+        }
+    }
+    if constexpr (EPI == EPI_BCE || EPI == EPI_MSE) {
+        const float tot = block_sum_256(lsum, sred);
+        if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+int small_gemm_blocks(const GemmArgs& a) { return ((a.M + ST - 1) / ST) * ((a.N + ST - 1) / ST); }
+
+template <int ALAY, int BLAY, int EPI>
+static void launch_small_t(hipStream_t s, const GemmArgs& a) {
+    dim3 grid((a.N + ST - 1) / ST, (a.M + ST - 1) / ST);
+    SMRT_LAUNCH((small_gemm_kernel<ALAY, BLAY, EPI>), grid, dim3(256), 0, s, a);
+}
+
+void launch_small_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a) {
+    if (kind == GEMM_NN) {
+        if (epi == EPI_BIAS_ACT)         launch_small_t<INNER, OUTER, EPI_BIAS_ACT>(s, a);
+        else if (epi == EPI_BCE)         launch_small_t<INNER, OUTER, EPI_BCE>(s, a);
+        else if (epi == EPI_MSE)         launch_small_t<INNER, OUTER, EPI_MSE>(s, a);
+        else                             launch_small_t<INNER, OUTER, EPI_HEADS_SPLIT>(s, a);
+    } else {
+        if (epi == EPI_ACTGRAD)          launch_small_t<INNER, INNER, EPI_ACTGRAD>(s, a);
+        else                             launch_small_t<INNER, INNER, EPI_LATENT>(s, a);
+    }
+}
+
+// ------------------------------------------------------------------ weight + bias gradients of every layer, one launch
+// [X | 1]^T . dPre with K = rows of the mini-batch (no split-K: one slab); the virtual ones index gives the bias row.
+__global__ __launch_bounds__(256, 2) void small_dw_kernel(const DwArgs a) {
+    __shared__ float red[4 * ST * SRED];
+    const int t = blockIdx.x;
+    int li = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.n_layers; ++i) if (t >= a.L[i].tile_begin) li = i;
+    const DwLayer& L = a.L[li];
+    const int lt = t - L.tile_begin;
+    const int m0 = (lt / L.tiles_n) * ST, n0 = (lt % L.tiles_n) * ST;
+    const f32x4v v = small_tile<OUTER, OUTER, true>(L.A, L.lda, L.fi, L.B, L.ldb, L.fo, m0, n0, a.rows, red);
+    const int row = m0 + (threadIdx.x >> 3), col0 = n0 + (threadIdx.x & 7) * 4;
+    if (row <= L.fi) {                                   // row == fi is the bias gradient
+        float* dst = L.C + (long)row * L.ldc + col0;     // ldc % 4 == 0 and col0 % 4 == 0: aligned
+        if (col0 + 3 < L.fo) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (col0 + c < L.fo) dst[c] = v[c];
+        }
+    }
+}
+
+void launch_small_dw(hipStream_t s, const DwArgs& a) {
+    SMRT_LAUNCH(small_dw_kernel, dim3(a.total_tiles), dim3(256), 0, s, a);
+}
+
+}  // namespace smrt

@@ -195,6 +195,7 @@ static inline bool use_big_tiles(int M, int N) {
 
 int gemm_grid_blocks(int kind, const GemmArgs& a) {
     (void)kind;
+    if (a.M <= SMALL_M_MAX) return small_gemm_blocks(a);
     const int t = use_big_tiles(a.M, a.N) ? 128 : 64;
     return ((a.M + t - 1) / t) * ((a.N + t - 1) / t);
 }
@@ -211,6 +212,7 @@ static void launch_gemm_t(hipStream_t s, const GemmArgs& a) {
 }
 
 void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a) {
+    if (a.M <= SMALL_M_MAX) { launch_small_gemm(s, kind, epi, a); return; }
     if (kind == GEMM_NN) {
         if (epi == EPI_BIAS_ACT)         launch_gemm_t<INNER, OUTER, EPI_BIAS_ACT>(s, a);
         else if (epi == EPI_BCE)         launch_gemm_t<INNER, OUTER, EPI_BCE>(s, a);

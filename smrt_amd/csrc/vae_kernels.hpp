@@ -168,7 +168,11 @@ int  dw_opt_blocks(int total_tiles);
 int  fused_set_max_lds(int bytes);
 void launch_build_image(hipStream_t s, const float* Wflat, const int* tab, float* img, int n_f4);
 
+constexpr int SMALL_M_MAX = 512;    // mini-batches up to this many rows take the register-fed 32x32-tile kernels (small_gemm.hip)
 void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a);
+void launch_small_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a);
+int  small_gemm_blocks(const GemmArgs& a);
+void launch_small_dw(hipStream_t s, const DwArgs& a);
 int  gemm_grid_blocks(int kind, const GemmArgs& a);          // number of blocks (= BCE partial count)
 void launch_dw(hipStream_t s, const DwArgs& a, bool big);
 void launch_optimizer(hipStream_t s, const OptArgs& a, int* n_blocks_out);
