@@ -57,19 +57,35 @@ struct Stage {
             return;
         }
         // Edge tiles: branch-free.  Every lane loads 16 bytes from a CLAMPED in-bounds address (row clamped to the last
-        // real row, column quad clamped to the last quad of the leading dimension) and out-of-range components are
-        // then replaced by 0 (or by 1 for the virtual ones index) with selects.  The element-wise branched form costs
-        // hundreds of scalar/branch instructions per K-tile on every edge workgroup (a quarter of the tiles of a
-        // 450-wide layer).
+        // real row, column quad clamped to the last quad of the leading dimension); mask() later replaces the
+        // out-of-range components by 0 (or by 1 for the virtual ones index) with selects.  The selects must NOT sit
+        // here: they would make the wave wait for the loads before the K-tile's MFMAs instead of after them.
         const int ldq = (int)ld - 4;
+        if constexpr (LAY == INNER) {
+            const int row = tid >> 3, kq = (tid & 7) * 4;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p)
+                r[p] = *reinterpret_cast<const float4*>(g + (long)min(mn0 + row + 32 * p, MN_data - 1) * ld + min(k0 + kq, ldq));
+        } else {
+            constexpr int F4 = BMN / 4, RPP = GEMM_THREADS / F4;
+            const int krow = tid / F4, mq = (tid % F4) * 4;
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p)
+                r[p] = *reinterpret_cast<const float4*>(g + (long)min(k0 + krow + RPP * p, K - 1) * ld + min(mn0 + mq, ldq));
+        }
+    }
+
+    // Edge tiles only: zero (or one) what the clamped loads fetched from outside the matrix.  Same arguments as load().
+    __device__ __forceinline__ void mask(int mn0, int MN_data, int k0, int K, int tid, bool full) {
+        if (full) return;
         if constexpr (LAY == INNER) {
             const int row = tid >> 3, kq = (tid & 7) * 4;
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
                 const int mn = mn0 + row + 32 * p, k = k0 + kq;
-                const float4 t = *reinterpret_cast<const float4*>(g + (long)min(mn, MN_data - 1) * ld + min(k, ldq));
                 const bool in = mn < MN_data;
                 const float one = (ONES && mn == MN_data) ? 1.f : 0.f;
+                const float4 t = r[p];
                 float4 v;
                 v.x = (k     < K) ? (in ? t.x : one) : 0.f;
                 v.y = (k + 1 < K) ? (in ? t.y : one) : 0.f;
@@ -83,8 +99,8 @@ struct Stage {
 #pragma unroll
             for (int p = 0; p < PASSES; ++p) {
                 const int k = k0 + krow + RPP * p, mn = mn0 + mq;
-                const float4 t = *reinterpret_cast<const float4*>(g + (long)min(k, K - 1) * ld + min(mn, ldq));
                 const bool kin = k < K;
+                const float4 t = r[p];
                 float4 v;
                 v.x = kin ? (mn     < MN_data ? t.x : ((ONES && mn     == MN_data) ? 1.f : 0.f)) : 0.f;
                 v.y = kin ? (mn + 1 < MN_data ? t.y : ((ONES && mn + 1 == MN_data) ? 1.f : 0.f)) : 0.f;
@@ -161,6 +177,8 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda,
         const bool fk = (kbeg + BK <= kend);
         sa.load(A, lda, m0, M_data, kbeg, kend, tid, fullA && fk);
         sb.load(B, ldb, n0, N_data, kbeg, kend, tid, fullB && fk);
+        sa.mask(m0, M_data, kbeg, kend, tid, fullA && fk);
+        sb.mask(n0, N_data, kbeg, kend, tid, fullB && fk);
     }
     sa.store(ldsA, tid);
     sb.store(ldsB, tid);
@@ -209,6 +227,9 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda,
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);
         }
         if (more) {
+            const bool fk = (k0 + 2 * BK <= kend);
+            sa.mask(m0, M_data, k0 + BK, kend, tid, fullA && fk);
+            sb.mask(n0, N_data, k0 + BK, kend, tid, fullB && fk);
             sa.store(ldsA + (buf ^ 1) * SZA, tid);
             sb.store(ldsB + (buf ^ 1) * SZB, tid);
             if (bsum) sb.add_to(*bsum);
