@@ -29,25 +29,29 @@ constexpr int SRED = 33;               // LDS row stride of a partial tile
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// The four k-step values of one 8-wide k-block for this lane (k = kb + 4 h + s, s = 0..3), zero (or one, for the
-// virtual ones index of the bias gradient) outside the matrix.  Addresses are clamped in-bounds, values selected.
-template <int LAY, bool ONES>
+// The four k-step values of one 8-wide k-block for this lane (k = kb4 + s, s = 0..3; kb4 = block start + 4 h), loaded from a
+// clamped in-bounds address.  mask_kblock() then zeroes (or sets to one, for the virtual ones index of the bias gradient)
+// what lies outside the matrix -- LATER, when the values are about to be used: a select right behind the load would make the
+// wave wait for its prefetch before multiplying the batch it already has.
+template <int LAY>
 __device__ __forceinline__ f32x4v load_kblock(const float* __restrict__ g, long ld, int mn, int MN_data, int kb4, int K) {
-    f32x4v v;
-    const bool in = mn < MN_data;
-    const float fill = (ONES && mn == MN_data) ? 1.f : 0.f;
     if constexpr (LAY == INNER) {       // [mn][k], k contiguous: one 16-byte load
-        const f32x4v t = *reinterpret_cast<const f32x4v*>(g + (long)min(mn, MN_data - 1) * ld + min(kb4, (int)ld - 4));
-#pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = (kb4 + s < K) ? (in ? t[s] : fill) : 0.f;
+        return *reinterpret_cast<const f32x4v*>(g + (long)min(mn, MN_data - 1) * ld + min(kb4, (int)ld - 4));
     } else {                            // [k][mn], mn contiguous: four 4-byte loads, each 128 B contiguous per half-wave
         const float* p = g + min(mn, MN_data - 1);
+        f32x4v v;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float t = p[(long)min(kb4 + s, K - 1) * ld];
-            v[s] = (kb4 + s < K) ? (in ? t : fill) : 0.f;
-        }
+        for (int s = 0; s < 4; ++s) v[s] = p[(long)min(kb4 + s, K - 1) * ld];
+        return v;
     }
+}
+template <bool ONES>
+__device__ __forceinline__ f32x4v mask_kblock(f32x4v t, int mn, int MN_data, int kb4, int K) {
+    const bool in = mn < MN_data;
+    const float fill = (ONES && mn == MN_data) ? 1.f : 0.f;
+    f32x4v v;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) v[s] = (kb4 + s < K) ? (in ? t[s] : fill) : 0.f;
     return v;
 }
 
@@ -70,13 +74,23 @@ __device__ __forceinline__ f32x4v small_tile(const float* __restrict__ A, long l
     auto fetch = [&](int first, f32x4v (&xa)[SG], f32x4v (&xb)[SG]) {
 #pragma unroll
         for (int j = 0; j < SG; ++j) {
-            // blocks past the end read a clamped address and select zeros (kb4 >= K)
-            const int kb4 = ((first + j) * 4 + wave) * 8 + 4 * h;
-            xa[j] = load_kblock<ALAY, A_ONES>(A, lda, m0 + r, M_data, kb4, K);
-            xb[j] = load_kblock<BLAY, false>(B, ldb, n0 + r, N_data, kb4, K);
+            const int kb4 = ((first + j) * 4 + wave) * 8 + 4 * h;      // blocks past the end read a clamped address
+            xa[j] = load_kblock<ALAY>(A, lda, m0 + r, M_data, kb4, K);
+            xb[j] = load_kblock<BLAY>(B, ldb, n0 + r, N_data, kb4, K);
         }
     };
-    if (mine > 0) fetch(0, fa, fb);
+    // interior tiles with K a multiple of 8 need no masking at all (wave-uniform)
+    const bool clean = (m0 + ST <= M_data) && (n0 + ST <= N_data) && ((K & 7) == 0);
+    auto mask = [&](int first, f32x4v (&xa)[SG], f32x4v (&xb)[SG]) {
+        if (clean) return;
+#pragma unroll
+        for (int j = 0; j < SG; ++j) {
+            const int kb4 = ((first + j) * 4 + wave) * 8 + 4 * h;
+            xa[j] = mask_kblock<A_ONES>(xa[j], m0 + r, M_data, kb4, K);
+            xb[j] = mask_kblock<false>(xb[j], n0 + r, N_data, kb4, K);
+        }
+    };
+    if (mine > 0) { fetch(0, fa, fb); mask(0, fa, fb); }
 #pragma unroll 1
     for (int i = 0; i < mine; i += SG) {
         const bool more = i + SG < mine;
@@ -94,6 +108,7 @@ __device__ __forceinline__ f32x4v small_tile(const float* __restrict__ A, long l
         if (more) {
 #pragma unroll
             for (int j = 0; j < SG; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
+            mask(i + SG, fa, fb);
         }
     }
     // the four waves' partial tiles meet in LDS
