@@ -169,45 +169,41 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
         for (int n0 = wave * 16; n0 < N16; n0 += 16 * FWAVES) {
             const int n = n0 + c;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-            // 64-wide k batches (4 k-blocks, 16 MFMAs into 4 independent chains).  The fragments of batch i+1 are
-            // requested BEFORE the MFMAs of batch i (the empty asm pins the order: left alone, hipcc sinks every LDS
-            // read to its first use and each k-block then pays the full LDS latency); look-ahead addresses are
-            // clamped (a harmless re-read), k-blocks past K16 are skipped by a uniform branch.
-            const int klast = K16 - 16;
-            f32x4 av[4], bv[4], an[4], bn[4];
-            const float* bpn = lds + w_off + ((q * nn + n) << 2);                               // forward image walk
-            const float* bpt = lds + w_off + ((((n >> 2) * nn) + 4 * q) << 2) + (n & 3);        // backward image walk
-            auto fetch = [&](int kb, f32x4 (&fa)[4], f32x4 (&fb)[4]) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int k = min(kb + 16 * j, klast);
-                    fa[j] = *reinterpret_cast<const f32x4*>(ap + k);
-                    if (!trans) {
-                        fb[j] = *reinterpret_cast<const f32x4*>(bpn + k * nn);      // Wop[k][n] = W[kf = k][nf = n]
-                    } else {
-                        const float* p = bpt + (k << 2);                           // Wop[k][n] = W[kf = n][nf = k]
-                        fb[j][0] = p[0]; fb[j][1] = p[4]; fb[j][2] = p[8]; fb[j][3] = p[12];
-                    }
-                }
-            };
-            fetch(0, av, bv);
+            // 128-wide k chunks (8 k-blocks of 16): ALL of a chunk's fragments are requested first, straight-line, then
+            // its 32 MFMAs run into 4 independent chains while the later reads are still landing (the compiler counts
+            // lgkmcnt down block by block).  Nets on this path have K <= 128 almost always, i.e. one chunk per stage.
+            // k-blocks past K16 are skipped by wave-uniform branches; no clamped addresses, no per-block selects.
+            const int nb_all = K16 >> 4;
 #pragma unroll 1
-            for (int k0 = 0; k0 < K16; k0 += 64) {
-                const bool more = (k0 + 64) < K16;
-                if (more) fetch(k0 + 64, an, bn);
-                asm volatile("" ::: "memory");
-                const int nblk = min(4, (K16 - k0) >> 4);
+            for (int kc = 0; kc < nb_all; kc += 8) {
+                const int nb = min(8, nb_all - kc);
+                f32x4 av[8], bv[8];
+                const float* apc = ap + kc * 16;
+                if (!trans) {
+                    const float* bp = lds + w_off + (((q + kc * 4) * nn + n) << 2);      // Wop[k][n] = W[kf = k][nf = n]
+                    const int bstep = nn << 4;                                           // 16 k = 4 k-quads of nn float4
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j < nblk) {
+                    for (int j = 0; j < 8; ++j)
+                        if (j < nb) {
+                            av[j] = *reinterpret_cast<const f32x4*>(apc + 16 * j);
+                            bv[j] = *reinterpret_cast<const f32x4*>(bp + j * bstep);
+                        }
+                } else {
+                    const float* bp = lds + w_off + ((((n >> 2) * nn) + 4 * q + kc * 16) << 2) + (n & 3);   // Wop[k][n] = W[kf = n][nf = k]
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j < nb) {
+                            av[j] = *reinterpret_cast<const f32x4*>(apc + 16 * j);
+                            const float* p = bp + 64 * j;
+                            bv[j][0] = p[0]; bv[j][1] = p[4]; bv[j][2] = p[8]; bv[j][3] = p[12];
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < nb) {
                         MFMA16(av[j][0], bv[j][0], acc0); MFMA16(av[j][1], bv[j][1], acc1);
                         MFMA16(av[j][2], bv[j][2], acc2); MFMA16(av[j][3], bv[j][3], acc3);
                     }
-                }
-                if (more) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { av[j] = an[j]; bv[j] = bn[j]; }
-                }
             }
             float v[4];
 #pragma unroll
