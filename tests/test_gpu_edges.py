@@ -1,0 +1,106 @@
+"""Boundaries between the three kernel families (fused small-net / small-batch register-fed / LDS-tiled), extreme shapes,
+and size-independent properties at BASELINE.json's full C2 size (1M x 64) where the oracle would take minutes."""
+import numpy as np
+import pytest
+
+from oracle.vae_oracle import OracleVAE, flatten_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, what, rtol=1e-4):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=rtol * max(np.abs(b).max(), 1e-30), err_msg=what)
+
+
+def _pair(D, hidden, Z, act, opt, max_batch, rs, seed=3):
+    from smrt_amd import _hip
+    o = OracleVAE(D, hidden, Z, activation=act, learning_function=opt, learning_rate=0.01, seed=seed)
+    o.params = [((W + 0.05 * rs.normal(size=W.shape)).astype(np.float32), (b + 0.05 * rs.normal(size=b.shape)).astype(np.float32))
+                for W, b in o.params]
+    h = _hip.VaeHandle(n_features=D, hidden=hidden, n_latent=Z, activation=act, optimizer=opt, learning_rate=0.01,
+                       l2_penalty=1e-4, clip=True, gclip_min=-5.0, gclip_max=5.0, eps=1e-10, dropout=1.0, seed=seed,
+                       max_batch=max_batch, device=0)
+    h.set_params(flatten_params(o.params))
+    return o, h
+
+
+@pytest.mark.parametrize("rows", [511, 512, 513, 640])
+def test_small_batch_to_tiled_kernel_boundary(rows):
+    """rows <= 512 run the register-fed 32x32 kernels, 513+ the LDS-tiled ones: same numbers either side."""
+    rs = np.random.RandomState(rows)
+    D, hidden, Z = 200, [300], 7                       # does not fit the fused small-net kernel (weights > 150 KB)
+    # rms_prop: Adam's first step is lr * g / (|g| + 1e-8), ill-conditioned for the few |g| ~ 1e-8 entries whatever the kernel
+    o, h = _pair(D, hidden, Z, "sigmoid", "rms_prop", rows, rs)
+    X, eps = rs.uniform(0, 1, size=(rows, D)), rs.normal(size=(rows, Z))
+    c_o, (gW, gb) = o.train_step(X, eps, return_grads=True)
+    c_h, g_h = h.train_step(X, eps, want_grads=True)
+    assert np.isclose(c_h, c_o, rtol=1e-4), (c_h, c_o)
+    _close(g_h, np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in zip(gW, gb)]), "gradients")
+    _close(h.get_params(), flatten_params(o.params), "params")
+    h.close()
+
+
+def test_six_hidden_layers_single_latent_batch_of_one():
+    """SMRT_MAX_HIDDEN layers, Z = 1, widths that are multiples of nothing, batches of 1 / 2 / 33 rows."""
+    rs = np.random.RandomState(12)
+    D, hidden, Z = 13, [11, 9, 7, 6, 5, 3], 1
+    o, h = _pair(D, hidden, Z, "tanh", "rms_prop", 33, rs)
+    for B in (1, 2, 33):
+        X, eps = rs.uniform(0, 1, size=(B, D)), rs.normal(size=(B, Z))
+        c_o = o.train_step(X, eps)
+        c_h = h.train_step(X, eps)
+        assert np.isclose(c_h, c_o, rtol=1e-4), (B, c_h, c_o)
+    _close(h.get_params(), flatten_params(o.params), "params", rtol=2e-4)
+    mu, ls = h.encode(rs.uniform(size=(3, D)))
+    assert mu.shape == (3, 1) and ls.shape == (3, 1)
+    h.close()
+    from smrt_amd import _hip
+    with pytest.raises(ValueError):
+        _hip.VaeHandle(n_features=4, hidden=[3] * 7, n_latent=2, activation="relu", optimizer="sgd", learning_rate=0.1,
+                       l2_penalty=None, clip=False, gclip_min=-5.0, gclip_max=5.0, eps=1e-10, dropout=1.0, seed=1, max_batch=4)
+
+
+def test_wide_net_epochs_match_oracle_fit():
+    """A 3 x 256-wide net over a ragged schedule (700 rows, batch 300 -> 300, 300, 100) through train_epochs, graph replay
+    included: epoch costs (last batch of each epoch) and parameters against the oracle's fit."""
+    rs = np.random.RandomState(21)
+    D, hidden, Z = 96, [256, 256, 256], 24
+    o, h = _pair(D, hidden, Z, "relu", "rms_prop", 300, rs)          # not Adam: see the boundary test above
+    X = rs.uniform(0, 1, size=(700, D))
+    costs, _ = h.train_epochs(X, 300, 3)
+    o.fit(X, n_epochs=3, batch_size=300)
+    np.testing.assert_allclose(costs, np.asarray(o.epoch_costs_, np.float32), rtol=2e-4)
+    _close(h.get_params(), flatten_params(o.params), "params after 3 epochs", rtol=5e-4)
+    h.close()
+
+
+def test_c2_full_size_balance_properties():
+    """BASELINE configs[1] at full size (1M x 64, 1:50): properties that need no oracle -- class counts reach the target,
+    the shuffle is a permutation that leaves every original row bit-identical, synthetic rows are sigmoid outputs in
+    (0, 1), labels follow their rows, and two runs with the same seed agree bit for bit."""
+    from smrt_amd.balance import smrt_balance
+    rs = np.random.RandomState(42)
+    n, n_minor, D = 1000000, 19608, 64
+    y = np.zeros(n, dtype=np.int64)
+    y[rs.choice(n, n_minor, replace=False)] = 1
+    X = (1.0 / (1.0 + np.exp(-(rs.normal(size=(n, D)).astype(np.float32) + rs.normal(size=(2, D)).astype(np.float32)[y]))))
+    X[:, 0] = np.arange(n, dtype=np.float32) / n            # a unique tag per original row
+    kw = dict(n_hidden=128, n_latent_factors=16, balance_ratio=0.2, random_state=42, n_epochs=3)
+    Xb, yb = smrt_balance(X, y, **kw)
+    target = int(0.2 * (n - n_minor))
+    assert Xb.shape == (n + target - n_minor, D) and Xb.dtype == np.float64
+    assert (yb == 1).sum() == target and (yb == 0).sum() == n - n_minor
+    tags = np.round(Xb[:, 0] * n).astype(np.int64)
+    is_orig = np.zeros(len(yb), dtype=bool)
+    cand = np.where((tags >= 0) & (tags < n))[0]            # fp32(i / n) * n is within 0.06 of i: rounding recovers the tag
+    match = cand[(Xb[cand] == X[tags[cand]].astype(np.float64)).all(axis=1)]
+    is_orig[match] = True
+    assert is_orig.sum() == n                                                   # every original row, unchanged
+    assert np.array_equal(np.sort(tags[is_orig]), np.arange(n))                 # each exactly once
+    assert np.array_equal(yb[is_orig], y[tags[is_orig]])                        # labels travel with their rows
+    synth = Xb[~is_orig]
+    assert synth.shape[0] == target - n_minor and (yb[~is_orig] == 1).all()
+    assert np.isfinite(synth).all() and synth.min() > 0.0 and synth.max() < 1.0
+    Xb2, yb2 = smrt_balance(X, y, **kw)
+    assert np.array_equal(Xb, Xb2) and np.array_equal(yb, yb2)
