@@ -115,6 +115,14 @@ def rup4(v):
     return (int(v) + 3) & ~3
 
 
+def sync_torch_stream(device):
+    """Wait for the work PyTorch has queued on its current stream of ``device`` (uploads, fills) before the library's
+    own stream touches the same memory.  Deliberately NOT ``torch.cuda.synchronize``: a device-wide synchronise is
+    refused by the runtime while any stream of the process is being captured, and ``smrt_balance`` fits classes
+    concurrently, each thread capturing its own epoch graph."""
+    _torch().cuda.current_stream(device).synchronize()
+
+
 def to_device_padded(array, device):
     """Host [n, d] array -> contiguous fp32 device tensor [n, rup4(d)]; returns (tensor, ld)."""
     torch = _torch()
@@ -124,7 +132,7 @@ def to_device_padded(array, device):
     t = torch.zeros((n, ld), dtype=torch.float32, device=device)
     if n:
         t[:, :d] = torch.from_numpy(a).to(device)
-    torch.cuda.synchronize(device)
+    sync_torch_stream(device)
     return t, ld
 
 
@@ -257,7 +265,7 @@ class VaeHandle(object):
             eps_t = torch.from_numpy(np.ascontiguousarray(eps, dtype=np.float32)).to(self.device)
             assert eps_t.shape == (rows, self.n_latent)
             eps_ptr = eps_t.data_ptr()
-        torch.cuda.synchronize(self.device)
+        sync_torch_stream(self.device)
         cost = C.c_float()
         grads = np.empty(self.n_params, dtype=np.float32) if want_grads else None
         _check(self._lib.smrt_vae_train_step(self._live(), Xt.data_ptr(), ldx, rows, eps_ptr, C.byref(cost),
@@ -304,12 +312,12 @@ class VaeHandle(object):
         if eps is not None:
             eps_t = torch.from_numpy(np.ascontiguousarray(eps, dtype=np.float32)).to(self.device)
             eps_ptr = eps_t.data_ptr()
-        torch.cuda.synchronize(self.device)
+        sync_torch_stream(self.device)
         _check(self._lib.smrt_vae_grad_step(self._live(), Xt.data_ptr(), ldx, Xt.shape[0], int(global_rows),
                                             int(row0_global), eps_ptr, grads_tensor.data_ptr()), "smrt_vae_grad_step")
 
     def apply_grads(self, grads_tensor):
-        _torch().cuda.synchronize(self.device)
+        sync_torch_stream(self.device)
         cost = C.c_float()
         _check(self._lib.smrt_vae_apply_grads(self._live(), grads_tensor.data_ptr(), C.byref(cost)), "smrt_vae_apply_grads")
         return np.float32(cost.value)
@@ -349,12 +357,12 @@ class VaeHandle(object):
         n = Xt.shape[0]
         mu = torch.empty((n, self.code_width), dtype=torch.float32, device=self.device)
         if self.model == "ae":                          # the code of the plain auto-encoder: one array
-            torch.cuda.synchronize(self.device)
+            sync_torch_stream(self.device)
             if n:
                 _check(self._lib.smrt_vae_encode(self._live(), Xt.data_ptr(), ldx, n, mu.data_ptr(), None), "smrt_vae_encode")
             return mu.cpu().numpy() if to_host else mu
         ls = torch.empty((n, self.n_latent), dtype=torch.float32, device=self.device)
-        torch.cuda.synchronize(self.device)
+        sync_torch_stream(self.device)
         if n:
             _check(self._lib.smrt_vae_encode(self._live(), Xt.data_ptr(), ldx, n, mu.data_ptr(), ls.data_ptr()),
                    "smrt_vae_encode")
@@ -366,7 +374,7 @@ class VaeHandle(object):
         n = Zt.shape[0]
         out = torch.empty((n, self.n_features), dtype=torch.float32, device=self.device) \
             if self.n_features % 4 == 0 else torch.empty((n, rup4(self.n_features)), dtype=torch.float32, device=self.device)
-        torch.cuda.synchronize(self.device)
+        sync_torch_stream(self.device)
         if n:
             _check(self._lib.smrt_vae_decode(self._live(), Zt.data_ptr(), ldz, n, out.data_ptr(), out.shape[1]),
                    "smrt_vae_decode")
@@ -376,7 +384,7 @@ class VaeHandle(object):
     def generate(self, n, philox_offset=0, loc=0.0, scale=1.0, to_host=True):
         torch = _torch()
         out = torch.empty((n, rup4(self.n_features)), dtype=torch.float32, device=self.device)
-        torch.cuda.synchronize(self.device)
+        sync_torch_stream(self.device)
         if n:
             _check(self._lib.smrt_vae_generate(self._live(), n, int(philox_offset), float(loc), float(scale),
                                                out.data_ptr(), out.shape[1]), "smrt_vae_generate")
@@ -386,7 +394,7 @@ class VaeHandle(object):
     def sample_eps(self, step, row0, rows):
         torch = _torch()
         out = torch.empty((rows, self.n_latent), dtype=torch.float32, device=self.device)
-        torch.cuda.synchronize(self.device)
+        sync_torch_stream(self.device)
         _check(self._lib.smrt_vae_sample_eps(self._live(), int(step), int(row0), int(rows), out.data_ptr()),
                "smrt_vae_sample_eps")
         return out.cpu().numpy()

@@ -21,6 +21,8 @@ What is different under the hood:
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .. import _hip
@@ -124,40 +126,67 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
     y_out_codes = np.empty(n_total, dtype=y_codes.dtype)
     y_out_codes[:n_orig] = y_codes
 
-    # ---- per-class train-then-generate (smrt.py:197-238); class order fixes the stream order
-    blocks, cursor = [], 0
+    # ---- per-class train (smrt.py:197-223).  A fit draws nothing from the shared numpy stream (it only reads the seed),
+    # so the fits of the classes this rank owns are independent jobs: they run concurrently, one host thread and one
+    # HIP stream each (ctypes releases the GIL; a default-batch step keeps 8-120 of the 256 CUs busy, so several fit in
+    # one GPU side by side), and the draws below still happen in class order.
+    import torch
+    device = torch.cuda.current_device() if torch.cuda.is_available() else 0      # worker threads do not inherit it
+    subs, fits, pool = [], [], None
+    n_threads = max(1, int(os.environ.get("SMRT_CLASS_THREADS", "8")))
     for j, (code, label, n_sub, need) in enumerate(jobs):
-        mine = owners[j] == rank
         X_sub = X[y_codes == code, :]
-        encoder = prefit_estimators.get(label, None)
-        fresh = encoder is None
-        if mine:
-            if fresh:
-                encoder = VariationalAutoEncoder(
-                    n_hidden=n_hidden, n_latent_factors=n_latent_factors, activation_function=activation_function,
-                    learning_rate=learning_rate, n_epochs=n_epochs, batch_size=batch_size, min_change=min_change,
-                    verbose=verbose, display_step=display_step, learning_function=learning_function,
-                    early_stopping=early_stopping, bias_strategy=bias_strategy, random_state=seeded_random_state,
-                    layer_type=layer_type, dropout=dropout, l2_penalty=l2_penalty, eps=eps, gclip_min=gclip_min,
-                    gclip_max=gclip_max, clip=clip).fit(X_sub)
-            encoders[label] = encoder
-            if not gen_from_samples:
-                synthetic = encoder.generate(n=need, **generate_args)
+        subs.append(X_sub)
+        if owners[j] != rank or prefit_estimators.get(label, None) is not None:
+            fits.append(None)
+            continue
+        est = VariationalAutoEncoder(
+            n_hidden=n_hidden, n_latent_factors=n_latent_factors, activation_function=activation_function,
+            learning_rate=learning_rate, n_epochs=n_epochs, batch_size=batch_size, min_change=min_change,
+            verbose=verbose, display_step=display_step, learning_function=learning_function,
+            early_stopping=early_stopping, bias_strategy=bias_strategy, random_state=seeded_random_state,
+            layer_type=layer_type, dropout=dropout, l2_penalty=l2_penalty, eps=eps, gclip_min=gclip_min,
+            gclip_max=gclip_max, clip=clip)
+        est.device = device
+        fits.append(est)
+    n_fresh = sum(f is not None for f in fits)
+    if n_fresh > 1 and n_threads > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=min(n_threads, n_fresh))
+        fits = [None if f is None else pool.submit(f.fit, X_sub) for f, X_sub in zip(fits, subs)]
+
+    # ---- per-class generate (smrt.py:226-238); class order fixes the stream order
+    blocks, cursor = [], 0
+    try:
+        for j, (code, label, n_sub, need) in enumerate(jobs):
+            mine = owners[j] == rank
+            X_sub = subs[j]
+            encoder = prefit_estimators.get(label, None)
+            fresh = encoder is None
+            if mine:
+                if fresh:
+                    encoder = fits[j].result() if pool is not None else fits[j].fit(X_sub)
+                encoders[label] = encoder
+                if not gen_from_samples:
+                    synthetic = encoder.generate(n=need, **generate_args)
+                else:
+                    sample_idcs = random_state.choice(np.arange(n_sub), size=need, replace=True)
+                    synthetic = encoder.generate_from_sample(X_sub[sample_idcs, :], **generate_args)
+                synth[cursor:cursor + need] = np.asarray(synthetic)
             else:
-                sample_idcs = random_state.choice(np.arange(n_sub), size=need, replace=True)
-                synthetic = encoder.generate_from_sample(X_sub[sample_idcs, :], **generate_args)
-            synth[cursor:cursor + need] = np.asarray(synthetic)
-        else:
-            # another rank owns this class: consume exactly the draws it makes on the shared stream
-            if gen_from_samples:
-                random_state.choice(np.arange(n_sub), size=need, replace=True)
-            shares_stream = fresh or getattr(encoder, "random_state_", None) is seeded_random_state
-            if shares_stream:
-                z_dim = resolve_latent(n_latent_factors, n_features) if fresh else int(encoder.n_latent_factors)
-                random_state.normal(size=(need, z_dim))
-        blocks.append((cursor, need, owners[j], mine))
-        y_out_codes[n_orig + cursor:n_orig + cursor + need] = code
-        cursor += need
+                # another rank owns this class: consume exactly the draws it makes on the shared stream
+                if gen_from_samples:
+                    random_state.choice(np.arange(n_sub), size=need, replace=True)
+                shares_stream = fresh or getattr(encoder, "random_state_", None) is seeded_random_state
+                if shares_stream:
+                    z_dim = resolve_latent(n_latent_factors, n_features) if fresh else int(encoder.n_latent_factors)
+                    random_state.normal(size=(need, z_dim))
+            blocks.append((cursor, need, owners[j], mine))
+            y_out_codes[n_orig + cursor:n_orig + cursor + need] = code
+            cursor += need
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
 
     if world > 1:
         for start, need, owner, mine in blocks:

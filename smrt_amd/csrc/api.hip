@@ -236,15 +236,16 @@ static void plan_fused(smrt_vae* h) {
     if (h->fused && bytes > 48 * 1024 && fused_set_max_lds(bytes) != 0) { (void)hipGetLastError(); h->fused = false; }
 }
 
-template <class T> static int dalloc(T** p, size_t n_elems) {
+// Zero-fills go on the handle's stream and are waited for there: a device-wide synchronise is refused by the runtime
+// while ANY stream of the process is being captured, and other host threads capture their own handles' epochs.
+template <class T> static int dalloc(T** p, size_t n_elems, hipStream_t s) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
     if (n_elems == 0) return 0;
     hipError_t e = hipMalloc((void**)p, n_elems * sizeof(T));
     if (e != hipSuccess) return fail(-3, std::string("hipMalloc: ") + hipGetErrorString(e));
-    e = hipMemset(*p, 0, n_elems * sizeof(T));
-    if (e != hipSuccess) return fail(-3, std::string("hipMemset: ") + hipGetErrorString(e));
-    e = hipDeviceSynchronize();       // the handle's stream is non-blocking: make the zero-fill visible to it
-    if (e != hipSuccess) return fail(-3, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e));
+    e = hipMemsetAsync(*p, 0, n_elems * sizeof(T), s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return fail(-3, std::string("zero-fill: ") + hipGetErrorString(e));
     return 0;
 }
 #define TRY(expr) do { int rc__ = (expr); if (rc__) return rc__; } while (0)
@@ -253,13 +254,13 @@ template <class T> static void carve(Arena& a, T** p, size_t n_elems) {
     *p = (n_elems && a.base) ? reinterpret_cast<T*>(a.base + a.off) : nullptr;
     a.off += (n_elems * sizeof(T) + 255) & ~size_t(255);
 }
-static int arena_alloc(Arena& a, size_t bytes) {
+static int arena_alloc(Arena& a, size_t bytes, hipStream_t s) {
     if (a.base) { (void)hipFree(a.base); a.base = nullptr; }
     a.cap = (bytes + (2u << 20) - 1) & ~size_t((2u << 20) - 1);
     hipError_t e = hipMalloc((void**)&a.base, a.cap);
     if (e != hipSuccess) { a.base = nullptr; return fail(-3, std::string("hipMalloc: ") + hipGetErrorString(e)); }
-    e = hipMemset(a.base, 0, a.cap);
-    if (e == hipSuccess) e = hipDeviceSynchronize();   // the handle's stream is non-blocking: make the zero-fill visible to it
+    e = hipMemsetAsync(a.base, 0, a.cap, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return fail(-3, std::string("arena zero-fill: ") + hipGetErrorString(e));
     return 0;
 }
@@ -320,7 +321,7 @@ static int ensure_train(smrt_vae* h, int rows) {
     };
     Arena dry;
     layout(dry);
-    TRY(arena_alloc(h->ta, dry.off));
+    TRY(arena_alloc(h->ta, dry.off, h->stream));
     layout(h->ta);
     h->g_splits_cap = nsplit;
     h->cap_rows = cap;
@@ -346,9 +347,9 @@ static int ensure_train(smrt_vae* h, int rows) {
 
 static int ensure_infer(smrt_vae* h, long rows) {
     if (rows <= h->icap) return 0;
-    TRY(dalloc(&h->ibuf[0], (size_t)rows * h->maxld));
-    TRY(dalloc(&h->ibuf[1], (size_t)rows * h->maxld));
-    TRY(dalloc(&h->izb, (size_t)rows * rup4(h->Z)));
+    TRY(dalloc(&h->ibuf[0], (size_t)rows * h->maxld, h->stream));
+    TRY(dalloc(&h->ibuf[1], (size_t)rows * h->maxld, h->stream));
+    TRY(dalloc(&h->izb, (size_t)rows * rup4(h->Z), h->stream));
     h->icap = rows;
     return 0;
 }
@@ -650,7 +651,7 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
         };
         Arena dry;
         layout(dry);
-        if ((rc = arena_alloc(h->pa, dry.off))) return bail(rc);
+        if ((rc = arena_alloc(h->pa, dry.off, h->stream))) return bail(rc);
         layout(h->pa);
         h->cost_cap = 2;
     }
@@ -843,14 +844,25 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
         if (hit) graphed = true;
         else {
             drop_graph(h);
-            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
                 int rc = enqueue_epoch(h->cost_dev);
                 hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
                 if (rc == 0 && e == hipSuccess && h->graph &&
                     hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0) == hipSuccess) {
                     graphed = true;
                     h->g_X = X_dev; h->g_ldx = ldx; h->g_n = n_rows; h->g_batch = batch_size;
-                } else { (void)hipGetLastError(); drop_graph(h); if (rc) return rc; }
+                } else {
+                    (void)hipGetLastError(); drop_graph(h);
+                    if (e != hipSuccess) {
+                        // The capture was invalidated (another host thread made a call the runtime forbids during
+                        // captures): the stream can stay refused afterwards, so run eagerly on a fresh one.
+                        hipStream_t fresh = nullptr;
+                        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess)
+                            return fail(-2, "train_epochs: capture failed and no new stream could be created");
+                        (void)hipStreamDestroy(h->own_stream);
+                        h->own_stream = h->stream = fresh;
+                    } else if (rc) return rc;
+                }
             } else (void)hipGetLastError();
         }
     }

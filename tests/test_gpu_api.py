@@ -198,3 +198,28 @@ def test_smrt_balance_matches_oracle_end_to_end(gen_from_samples):
     assert Xb.shape == Xo.shape == (120 + 60 + 60 + 60, D)
     np.testing.assert_allclose(Xb, Xo, rtol=1e-3, atol=1e-5)
     assert enc[0] is None and all(enc[k] is not None for k in (1, 2, 3))
+
+
+@pytest.mark.gpu
+def test_smrt_balance_concurrent_class_fits_are_bit_identical(monkeypatch):
+    """Fits of several minority classes run concurrently (one host thread + HIP stream each); the result must equal the
+    sequential run bit for bit, estimators included (SURVEY 8e-1 applied inside one GPU)."""
+    from smrt_amd.balance import smrt_balance
+    rs = np.random.RandomState(8)
+    counts = {0: 400, 1: 60, 2: 45, 3: 90, 4: 30, 5: 250}
+    X = np.vstack([np.clip(rs.uniform(size=24) + 0.1 * rs.normal(size=(n, 24)), 0, 1) for n in counts.values()])
+    y = np.concatenate([np.full(n, k) for k, n in counts.items()])
+    p = rs.permutation(len(y))
+    X, y = X[p], y[p]
+    kw = dict(n_hidden=[20, 12], n_latent_factors=4, balance_ratio=0.5, n_epochs=4, batch_size=32, random_state=3,
+              return_estimators=True)
+    monkeypatch.setenv("SMRT_CLASS_THREADS", "1")
+    Xs, ys, es = smrt_balance(X, y, **kw)
+    monkeypatch.setenv("SMRT_CLASS_THREADS", "8")
+    Xt, yt, et = smrt_balance(X, y, **kw)
+    assert np.array_equal(Xs, Xt) and np.array_equal(ys, yt)
+    assert (ys == 1).sum() == 200 and (ys == 4).sum() == 200 and (ys == 5).sum() == 250
+    for label in (1, 2, 3, 4):
+        np.testing.assert_array_equal(es[label].sess.get_params(), et[label].sess.get_params())
+        np.testing.assert_array_equal(es[label].epoch_costs_, et[label].epoch_costs_)
+    assert es[0] is None and es[5] is None

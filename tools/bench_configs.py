@@ -145,6 +145,31 @@ def case_balance(name, which, reps=3):
             "out_dtype": str(Xb.dtype)}
 
 
+def case_balance_c3(name, threads):
+    """C3 on ONE GPU: 8 minority classes x 5 000 rows + 50 000 majority, 784-d, N1, API defaults (batch 128, 20 epochs):
+    the eight per-class jobs side by side (SMRT_CLASS_THREADS) or one after the other."""
+    from smrt_amd.balance import smrt_balance
+    rs = np.random.RandomState(42)
+    Xs, ys = [], []
+    for label, n in [(0, 50000)] + [(k, 5000) for k in range(1, 9)]:
+        proto, mask = rs.uniform(size=784), rs.uniform(size=784) < 0.2
+        Xs.append((np.clip(proto + 0.15 * rs.normal(size=(n, 784)), 0, 1) * mask).astype(np.float32))
+        ys.append(np.full(n, label))
+    X, y = np.vstack(Xs), np.concatenate(ys)
+    p = rs.permutation(len(y))
+    X, y = X[p], y[p]
+    os.environ["SMRT_CLASS_THREADS"] = str(threads)
+    kw = dict(n_hidden=450, n_latent_factors=10, balance_ratio=0.5, random_state=42)
+    smrt_balance(X[:9000], y[:9000], n_epochs=1, **kw)
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        Xb, yb = smrt_balance(X, y, **kw)
+        times.append(time.perf_counter() - t0)
+    return {"case": name, "config": "C3 on one GPU", "class_threads": threads, "in_rows": int(len(y)), "out_rows": int(len(yb)),
+            "wall_s_median": float(np.median(times)), "wall_s_all": times}
+
+
 CASES = {
     "train_n2_b128": lambda: case_train("train_n2_b128", "N2", 19608, 128, "rms_prop", 10),
     "train_n2_b4096": lambda: case_train("train_n2_b4096", "N2", 19608, 4096, "rms_prop", 20),
@@ -157,6 +182,8 @@ CASES = {
     "gen_n5": lambda: case_gen("gen_n5", "N5", 1000000, reps=3),
     "balance_c1": lambda: case_balance("balance_c1", "C1"),
     "balance_c2": lambda: case_balance("balance_c2", "C2"),
+    "balance_c3_seq": lambda: case_balance_c3("balance_c3_seq", 1),
+    "balance_c3_par": lambda: case_balance_c3("balance_c3_par", 8),
 }
 
 
