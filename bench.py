@@ -246,6 +246,15 @@ def main():
             "kernel_launches_per_step": sess.last_epoch_launches,
             "final_cost": float(costs[-1]),
         }
+        if world == 1:
+            # What the device itself allows: the fp32 MFMA rate a register-resident loop reaches, and the
+            # cost of the same launch pattern with no arithmetic in it (a captured chain of dependent 8-workgroup kernels).
+            k_per_mb = max(1, sess.last_epoch_launches // steps_per_epoch)
+            floor_us = _hip.diag_step_floor(local_rank, k_per_mb, steps_per_epoch, (BATCH + 15) // 16, 512)
+            roof["peak_measured"] = _hip.diag_mfma_peak(local_rank)
+            out["latency_floor"] = {"kernels_per_minibatch": k_per_mb, "us_per_minibatch": floor_us,
+                                    "ms_per_step": floor_us * steps_per_epoch / 1e3,
+                                    "frac_of_step": floor_us * steps_per_epoch / 1e3 / out["ms_per_step"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X)
         if world == 1 and not args.no_balance:

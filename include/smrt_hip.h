@@ -156,6 +156,17 @@ int  smrt_assemble_rows(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t
                         const float* synth, int64_t n_synth, int64_t ld_synth,
                         const int64_t* order, int64_t n_out, double* out, int32_t n_threads);
 
+/* ---- diagnostics: achievable peaks and the latency floor the roofline figures are quoted against.
+ * No counterpart in the reference; nothing on the product path calls them.
+ *   smrt_diag_mfma_peak     : register-resident v_mfma_f32_32x32x2_f32 loop on every CU -> TFLOP/s actually reachable.
+ *   smrt_diag_hbm_bandwidth : float4 copy (read+write) and read-only sweep over `bytes` of device memory -> GB/s.
+ *   smrt_diag_step_floor    : a captured graph of steps x kernels_per_step dependent one-word kernels of
+ *                             `workgroups` x `threads` -> microseconds per step with no arithmetic at all. */
+int  smrt_diag_mfma_peak(int32_t device, double* tflops);
+int  smrt_diag_hbm_bandwidth(int32_t device, int64_t bytes, double* copy_gbs, double* read_gbs);
+int  smrt_diag_step_floor(int32_t device, int32_t kernels_per_step, int32_t steps, int32_t workgroups,
+                          int32_t threads, double* us_per_step);
+
 const char* smrt_last_error(void);
 const char* smrt_version(void);
 

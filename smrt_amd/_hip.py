@@ -27,7 +27,8 @@ EXPORTS = [
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
-    "smrt_assemble_rows", "smrt_last_error", "smrt_version",
+    "smrt_assemble_rows", "smrt_diag_mfma_peak", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
+    "smrt_last_error", "smrt_version",
 ]
 
 
@@ -68,6 +69,10 @@ def load():
     lib.smrt_version.restype = C.c_char_p
     lib.smrt_vae_create.argtypes = [C.POINTER(VaeCfg), C.c_int, C.POINTER(vp)]
     lib.smrt_vae_destroy.argtypes = [vp]
+    dp = C.POINTER(C.c_double)
+    lib.smrt_diag_mfma_peak.argtypes = [i32, dp]
+    lib.smrt_diag_hbm_bandwidth.argtypes = [i32, i64, dp, dp]
+    lib.smrt_diag_step_floor.argtypes = [i32, i32, i32, i32, i32, dp]
     lib.smrt_vae_destroy.restype = None
     lib.smrt_vae_param_count.argtypes = [vp]; lib.smrt_vae_param_count.restype = i64
     lib.smrt_vae_dp_count.argtypes = [vp]; lib.smrt_vae_dp_count.restype = i64
@@ -134,6 +139,32 @@ def to_device_padded(array, device):
         t[:, :d] = torch.from_numpy(a).to(device)
     sync_torch_stream(device)
     return t, ld
+
+
+def diag_mfma_peak(device=0):
+    """fp32 MFMA TFLOP/s a register-resident loop reaches on ``device`` (include/smrt_hip.h: diagnostics)."""
+    _torch()
+    out = C.c_double()
+    _check(load().smrt_diag_mfma_peak(int(device), C.byref(out)), "smrt_diag_mfma_peak")
+    return out.value
+
+
+def diag_hbm_bandwidth(device=0, nbytes=1 << 30):
+    """(copy GB/s counting read + write, read-only GB/s) over ``nbytes`` of device memory."""
+    _torch()
+    c, r = C.c_double(), C.c_double()
+    _check(load().smrt_diag_hbm_bandwidth(int(device), C.c_int64(int(nbytes)), C.byref(c), C.byref(r)),
+           "smrt_diag_hbm_bandwidth")
+    return c.value, r.value
+
+
+def diag_step_floor(device=0, kernels_per_step=2, steps=154, workgroups=8, threads=512):
+    """Microseconds per step of a captured chain of dependent one-word kernels: the floor under a mini-batch step."""
+    _torch()
+    out = C.c_double()
+    _check(load().smrt_diag_step_floor(int(device), int(kernels_per_step), int(steps), int(workgroups), int(threads),
+                                       C.byref(out)), "smrt_diag_step_floor")
+    return out.value
 
 
 def assemble_rows(X, synth, order, n_threads=None):

@@ -22,6 +22,8 @@ What is different under the hood:
 from __future__ import annotations
 
 import os
+import sys
+import time
 
 import numpy as np
 
@@ -91,8 +93,17 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
     shared random state unless ``shuffle=False`` -- plus ``{label: estimator or None}`` when
     ``return_estimators``.
     """
+    timing = os.environ.get("SMRT_TIMING") == "1"
+    t_phase = [time.perf_counter()]
+
+    def lap(what):
+        if timing:
+            t_phase.append(time.perf_counter())
+            sys.stderr.write("[smrt_balance] %-10s %8.1f ms\n" % (what, 1e3 * (t_phase[-1] - t_phase[-2])))
+
     X, y, n_classes, present_classes, counts, majority_label, target_count = \
         validate_X_y_ratio_classes(X, y, balance_ratio, copy=False, keep_float32=True)
+    lap("validate")
 
     seeded_random_state = get_random_state(random_state)
     random_state = seeded_random_state.state
@@ -155,6 +166,7 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
         pool = ThreadPoolExecutor(max_workers=min(n_threads, n_fresh))
         fits = [None if f is None else pool.submit(f.fit, X_sub) for f, X_sub in zip(fits, subs)]
 
+    lap("submit")
     # ---- per-class generate (smrt.py:226-238); class order fixes the stream order
     blocks, cursor = [], 0
     try:
@@ -188,6 +200,7 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
         if pool is not None:
             pool.shutdown(wait=True)
 
+    lap("fit+gen")
     if world > 1:
         for start, need, owner, mine in blocks:
             got = _exchange_block(dist, synth[start:start + need] if mine else None, (need, n_features), owner)
@@ -201,6 +214,7 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
         output_order = random_state.permutation(np.arange(n_total))
         y_out = y_out[output_order]
     X_out = _hip.assemble_rows(X, synth, output_order)    # fp64 [X ; synthetic][order] in one pass
+    lap("assemble")
 
     if return_estimators:
         return X_out, y_out, encoders

@@ -15,6 +15,7 @@ using namespace smrt;
 static thread_local std::string g_err;
 namespace smrt { thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr; }
 static int fail(int code, const std::string& m) { g_err = m; return code; }
+int smrt_set_error(int code, const std::string& m) { return fail(code, m); }     // for diag.hip
 
 #define HIPC(expr)                                                                              \
     do {                                                                                        \

@@ -223,3 +223,18 @@ def test_smrt_balance_concurrent_class_fits_are_bit_identical(monkeypatch):
         np.testing.assert_array_equal(es[label].sess.get_params(), et[label].sess.get_params())
         np.testing.assert_array_equal(es[label].epoch_costs_, et[label].epoch_costs_)
     assert es[0] is None and es[5] is None
+
+
+@pytest.mark.gpu
+def test_diagnostic_peaks_are_sane():
+    """include/smrt_hip.h diagnostics: measured fp32 MFMA rate, HBM bandwidth and the empty-step floor land where an
+    MI355X can (nominal 157.3 TFLOP/s, 8 TB/s); the step-floor chain checks that every launch ran."""
+    from smrt_amd import _hip
+    tf = _hip.diag_mfma_peak(0)
+    assert 60.0 < tf < 1.02 * 157.3, tf
+    copy, read = _hip.diag_hbm_bandwidth(0, 1 << 28)
+    assert 1000.0 < copy < 8000.0 and 1000.0 < read < 8000.0, (copy, read)
+    us = _hip.diag_step_floor(0, 2, 50, 8, 512)
+    assert 0.5 < us < 100.0, us
+    with pytest.raises(_hip.HipLibraryError):
+        _hip.diag_step_floor(0, 0, 50, 8, 512)
