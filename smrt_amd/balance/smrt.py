@@ -138,9 +138,13 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
     y_out_codes[:n_orig] = y_codes
 
     # ---- per-class train (smrt.py:197-223).  A fit draws nothing from the shared numpy stream (it only reads the seed),
-    # so the fits of the classes this rank owns are independent jobs: they run concurrently, one host thread and one
-    # HIP stream each (ctypes releases the GIL; a default-batch step keeps 8-120 of the 256 CUs busy, so several fit in
-    # one GPU side by side), and the draws below still happen in class order.
+    # and every host draw of the generation step has a size known up front, so three things overlap:
+    #   * the fits of the classes this rank owns, one host thread and one HIP stream each (ctypes releases the GIL; a
+    #     default-batch step keeps 8-120 of the 256 CUs busy, so several fit in one GPU side by side);
+    #   * the main thread drawing, in class order, exactly what the reference draws between its fits (the re-draw
+    #     indices, the latent normals) and, last, the output permutation -- the sequential Mersenne-Twister work that
+    #     otherwise sits between the GPU phases;
+    #   * nothing else: decoding waits for the fit it belongs to.
     import torch
     device = torch.cuda.current_device() if torch.cuda.is_available() else 0      # worker threads do not inherit it
     subs, fits, pool = [], [], None
@@ -161,23 +165,31 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
         est.device = device
         fits.append(est)
     n_fresh = sum(f is not None for f in fits)
-    if n_fresh > 1 and n_threads > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=min(n_threads, n_fresh))
-        fits = [None if f is None else pool.submit(f.fit, X_sub) for f, X_sub in zip(fits, subs)]
+    lap("split")
 
-    lap("submit")
-    # ---- per-class generate (smrt.py:226-238); class order fixes the stream order
-    blocks, cursor = [], 0
+    blocks, cursor, drawn = [], 0, []
     try:
+        if n_fresh:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=min(n_threads, n_fresh))
+            fits = [None if f is None else pool.submit(f.fit, X_sub) for f, X_sub in zip(fits, subs)]
+
+        # ---- the shared stream, in class order (smrt.py:226-238 via autoencoder.py:519-572)
         for j, (code, label, n_sub, need) in enumerate(jobs):
             mine = owners[j] == rank
             X_sub = subs[j]
             encoder = prefit_estimators.get(label, None)
             fresh = encoder is None
-            if mine:
-                if fresh:
-                    encoder = fits[j].result() if pool is not None else fits[j].fit(X_sub)
+            noise = sample_idcs = None
+            if fresh:
+                if gen_from_samples:
+                    sample_idcs = random_state.choice(np.arange(n_sub), size=need, replace=True)
+                z_dim = resolve_latent(n_latent_factors, n_features)
+                noise = random_state.normal(size=(need, z_dim), **generate_args)
+                if not mine:
+                    noise = sample_idcs = None
+            elif mine:
+                # a caller-supplied estimator draws for itself, here, at its place in the order
                 encoders[label] = encoder
                 if not gen_from_samples:
                     synthetic = encoder.generate(n=need, **generate_args)
@@ -189,13 +201,31 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
                 # another rank owns this class: consume exactly the draws it makes on the shared stream
                 if gen_from_samples:
                     random_state.choice(np.arange(n_sub), size=need, replace=True)
-                shares_stream = fresh or getattr(encoder, "random_state_", None) is seeded_random_state
-                if shares_stream:
-                    z_dim = resolve_latent(n_latent_factors, n_features) if fresh else int(encoder.n_latent_factors)
-                    random_state.normal(size=(need, z_dim))
+                if getattr(encoder, "random_state_", None) is seeded_random_state:
+                    random_state.normal(size=(need, int(encoder.n_latent_factors)), **generate_args)
+            drawn.append((noise, sample_idcs))
             blocks.append((cursor, need, owners[j], mine))
             y_out_codes[n_orig + cursor:n_orig + cursor + need] = code
             cursor += need
+        output_order = random_state.permutation(np.arange(n_total)) if shuffle else None
+        lap("draws")
+
+        # ---- per-class generate for the fresh fits: decode what was drawn above
+        for j, (code, label, n_sub, need) in enumerate(jobs):
+            if fits[j] is None:
+                continue
+            encoder = fits[j].result()
+            encoders[label] = encoder
+            noise, sample_idcs = drawn[j]
+            start = blocks[j][0]
+            if not gen_from_samples:
+                synthetic = encoder.feed_forward(noise)                           # == generate(n=need, **generate_args)
+            else:
+                z_mu, log_sigma = encoder.encode(subs[j][sample_idcs, :])         # == generate_from_sample(...)
+                z_mu += noise * np.exp(log_sigma)
+                synthetic = encoder.feed_forward(z_mu)
+            synth[start:start + need] = np.asarray(synthetic)
+            drawn[j] = None
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
@@ -209,9 +239,7 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
 
     y_out = present_classes[y_out_codes]                  # back to the caller's label space (smrt.py:241)
 
-    output_order = None
     if shuffle:
-        output_order = random_state.permutation(np.arange(n_total))
         y_out = y_out[output_order]
     X_out = _hip.assemble_rows(X, synth, output_order)    # fp64 [X ; synthetic][order] in one pass
     lap("assemble")
