@@ -13,7 +13,10 @@
 using namespace smrt;
 
 static thread_local std::string g_err;
-namespace smrt { thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr; }
+namespace smrt {
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+thread_local GraphBuild g_build;
+}
 static int fail(int code, const std::string& m) { g_err = m; return code; }
 int smrt_set_error(int code, const std::string& m) { return fail(code, m); }     // for diag.hip
 
@@ -845,24 +848,21 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
         if (hit) graphed = true;
         else {
             drop_graph(h);
-            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
-                int rc = enqueue_epoch(h->cost_dev);
-                hipError_t e = hipStreamEndCapture(h->stream, &h->graph);
-                if (rc == 0 && e == hipSuccess && h->graph &&
+            // Build the epoch graph node by node (vae_kernels.hpp: GraphBuild) -- no stream is ever put into capture.
+            if (hipGraphCreate(&h->graph, 0) == hipSuccess) {
+                g_build = GraphBuild{};
+                g_build.graph = h->graph;
+                const int rc = enqueue_epoch(h->cost_dev);
+                const hipError_t e = g_build.err;
+                const long nodes = g_build.nodes;
+                g_build = GraphBuild{};
+                if (rc == 0 && e == hipSuccess && nodes > 0 &&
                     hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0) == hipSuccess) {
                     graphed = true;
                     h->g_X = X_dev; h->g_ldx = ldx; h->g_n = n_rows; h->g_batch = batch_size;
                 } else {
                     (void)hipGetLastError(); drop_graph(h);
-                    if (e != hipSuccess) {
-                        // The capture was invalidated (another host thread made a call the runtime forbids during
-                        // captures): the stream can stay refused afterwards, so run eagerly on a fresh one.
-                        hipStream_t fresh = nullptr;
-                        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess)
-                            return fail(-2, "train_epochs: capture failed and no new stream could be created");
-                        (void)hipStreamDestroy(h->own_stream);
-                        h->own_stream = h->stream = fresh;
-                    } else if (rc) return rc;
+                    if (rc) return rc;
                 }
             } else (void)hipGetLastError();
         }

@@ -139,10 +139,18 @@ extern "C" int smrt_diag_step_floor(int32_t device, int32_t kernels_per_step, in
     DIAGC(hipStreamSynchronize(s));
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    DIAGC(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-    for (long i = 0; i < (long)kernels_per_step * steps; ++i)
-        hipLaunchKernelGGL(diag_touch_kernel, dim3(workgroups), dim3(threads), 0, s, p);
-    DIAGC(hipStreamEndCapture(s, &graph));
+    DIAGC(hipGraphCreate(&graph, 0));
+    hipGraphNode_t prev = nullptr;
+    for (long i = 0; i < (long)kernels_per_step * steps; ++i) {
+        void* args[] = {(void*)&p};
+        hipKernelNodeParams kp{};
+        kp.func = (void*)diag_touch_kernel;
+        kp.gridDim = dim3(workgroups); kp.blockDim = dim3(threads); kp.sharedMemBytes = 0;
+        kp.kernelParams = args; kp.extra = nullptr;
+        hipGraphNode_t node = nullptr;
+        DIAGC(hipGraphAddKernelNode(&node, graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp));
+        prev = node;
+    }
     DIAGC(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     hipError_t err = hipSuccess;
     (void)hipGraphLaunch(exec, s);                            // warm-up (uploads the graph)

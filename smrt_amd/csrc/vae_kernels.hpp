@@ -4,6 +4,9 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <tuple>
+#include <utility>
+
 namespace smrt {
 
 constexpr int MAX_LAYERS = 16;      // internal dense layers: 2*L + 2 <= 14
@@ -12,9 +15,43 @@ constexpr int MAX_LAYERS = 16;      // internal dense layers: 2*L + 2 <= 14
 // through hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin / end times (what
 // rocprofv3 --kernel-trace reports), not with the time a separately recorded event happens to retire.
 extern thread_local hipEvent_t g_prof_start, g_prof_stop;
+
+// Epoch graphs are BUILT, not captured: while the host thread has a graph open (smrt_vae_train_epochs), every launch
+// becomes a kernel node chained behind the previous one.  Stream capture is avoided on purpose: while any stream of
+// the process is capturing, the runtime refuses device-wide synchronises and legacy-stream copies from every other
+// host thread, and smrt_balance trains several classes from several threads (PyTorch uploads on the legacy stream).
+struct GraphBuild {
+    hipGraph_t graph = nullptr;
+    hipGraphNode_t prev = nullptr;
+    hipError_t err = hipSuccess;
+    long nodes = 0;
+};
+extern thread_local GraphBuild g_build;
+
+template <class... KArgs, size_t... I>
+inline void smrt_arg_ptrs(std::tuple<KArgs...>& vals, void** ptrs, std::index_sequence<I...>) {
+    ((ptrs[I] = (void*)&std::get<I>(vals)), ...);
+}
+template <class... KArgs, class... Args>
+inline void smrt_add_node(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, Args&&... args) {
+    std::tuple<KArgs...> vals(std::forward<Args>(args)...);          // the kernel's exact parameter types
+    void* ptrs[sizeof...(KArgs)];
+    smrt_arg_ptrs(vals, ptrs, std::index_sequence_for<KArgs...>{});
+    hipKernelNodeParams kp{};
+    kp.func = (void*)kernel;
+    kp.gridDim = grid; kp.blockDim = block; kp.sharedMemBytes = (unsigned)shmem;
+    kp.kernelParams = ptrs; kp.extra = nullptr;
+    hipGraphNode_t node = nullptr;
+    const hipError_t e = hipGraphAddKernelNode(&node, g_build.graph, g_build.prev ? &g_build.prev : nullptr,
+                                               g_build.prev ? 1 : 0, &kp);
+    if (e == hipSuccess) { g_build.prev = node; ++g_build.nodes; }
+    else if (g_build.err == hipSuccess) g_build.err = e;
+}
+
 #define SMRT_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                   \
     do {                                                                                                      \
-        if (g_prof_start) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, g_prof_start, g_prof_stop, 0, __VA_ARGS__); \
+        if (smrt::g_build.graph) smrt::smrt_add_node(kernel, grid, block, shmem, __VA_ARGS__);                \
+        else if (g_prof_start) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, g_prof_start, g_prof_stop, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                             \
     } while (0)
 
