@@ -156,6 +156,28 @@ int  smrt_assemble_rows(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t
                         const float* synth, int64_t n_synth, int64_t ld_synth,
                         const int64_t* order, int64_t n_out, double* out, int32_t n_threads);
 
+/* Same pass with fp64 appended rows (smote_balance, smrt/balance/smote.py:93,254-260); with n_synth == 0 it is the row
+ * gather of over_sample_balance (over.py:77-81) and under_sample_balance (under.py:69-78). */
+int  smrt_assemble_rows_f64(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,
+                            const double* synth, int64_t n_synth, int64_t ld_synth,
+                            const int64_t* order, int64_t n_out, double* out, int32_t n_threads);
+
+/* ---- smote_balance (smrt/balance/smote.py).  All pointers are DEVICE memory; work is queued on hip_stream.
+ * smrt_knn_f64 replaces NearestNeighbors(...).fit(X_sub).kneighbors(X_sub, k, return_distance=False)
+ * (smote.py:53-69): for every query row the k candidate rows with the smallest sum_j (q_j - c_j)^2, accumulated in
+ * fp64 in feature order without fused multiply-adds (what sklearn's tree metric computes), sorted ascending, equal
+ * sums to the lower candidate row.  idx_out [nq][k]; rdist_out [nq][k] (the squared distances) may be NULL.
+ * Only the Euclidean metric (p = 2) is provided; 1 <= k <= min(64, nc). */
+int  smrt_knn_f64(const double* Q_dev, int64_t nq, int64_t ldq, const double* C_dev, int64_t nc, int64_t ldc,
+                  int64_t d, int32_t k, int64_t* idx_out_dev, double* rdist_out_dev, void* hip_stream);
+/* smrt_smote_rows_f64 replaces the strategy functions applied per neighbour (smote.py:22-29,84-89):
+ *   mode 0 'perturb'    : out[i] = (X[base[i]] - X[nbr[i]]) * r[i] + X[base[i]]      (each operation rounded, no FMA)
+ *   mode 1 'interpolate': out[i] = (X[base[i]] + X[nbr[i]]) / 2
+ * A row whose indices fall outside [0, n_x) is written as NaN, never read. */
+int  smrt_smote_rows_f64(const double* X_dev, int64_t n_x, int64_t ldx, int64_t d, const int64_t* base_idx_dev,
+                         const int64_t* nbr_idx_dev, const double* r_dev, int64_t n_rows, int32_t mode,
+                         double* out_dev, int64_t ldo, void* hip_stream);
+
 /* ---- diagnostics: achievable peaks and the latency floor the roofline figures are quoted against.
  * No counterpart in the reference; nothing on the product path calls them.
  *   smrt_diag_mfma_peak     : register-resident v_mfma_f32_32x32x2_f32 loop on every CU -> TFLOP/s actually reachable.

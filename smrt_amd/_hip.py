@@ -27,7 +27,7 @@ EXPORTS = [
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
-    "smrt_assemble_rows", "smrt_diag_mfma_peak", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
+    "smrt_assemble_rows", "smrt_assemble_rows_f64", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
     "smrt_last_error", "smrt_version",
 ]
 
@@ -70,6 +70,8 @@ def load():
     lib.smrt_vae_create.argtypes = [C.POINTER(VaeCfg), C.c_int, C.POINTER(vp)]
     lib.smrt_vae_destroy.argtypes = [vp]
     dp = C.POINTER(C.c_double)
+    lib.smrt_knn_f64.argtypes = [vp, i64, i64, vp, i64, i64, i64, i32, vp, vp, vp]
+    lib.smrt_smote_rows_f64.argtypes = [vp, i64, i64, i64, vp, vp, vp, i64, i32, vp, i64, vp]
     lib.smrt_diag_mfma_peak.argtypes = [i32, dp]
     lib.smrt_diag_hbm_bandwidth.argtypes = [i32, i64, dp, dp]
     lib.smrt_diag_step_floor.argtypes = [i32, i32, i32, i32, i32, dp]
@@ -96,6 +98,7 @@ def load():
     lib.smrt_vae_sample_eps.argtypes = [vp, i64, i64, i32, vp]
     lib.smrt_vae_profile_epochs.argtypes = [vp, vp, i64, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(i64)]
     lib.smrt_assemble_rows.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32]
+    lib.smrt_assemble_rows_f64.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32]
     _lib = lib
     return lib
 
@@ -167,17 +170,21 @@ def diag_step_floor(device=0, kernels_per_step=2, steps=154, workgroups=8, threa
     return out.value
 
 
-def assemble_rows(X, synth, order, n_threads=None):
+def assemble_rows(X, synth, order, n_threads=None, synth_dtype=np.float32):
     """fp64 ``[X ; synth][order]`` in one multi-threaded pass (``order`` None: plain concatenation).
 
-    ``X``: C-contiguous fp32/fp64 ``[n, d]``; ``synth``: fp32 ``[m, d]`` (may have 0 rows); ``order``: int64 row numbers.
-    Host-only: needs the library, not a GPU."""
+    ``X``: C-contiguous fp32/fp64 ``[n, d]``; ``synth``: ``[m, d]`` rows of ``synth_dtype`` (fp32: what the VAE kernels
+    produce; fp64: SMOTE rows), may be ``None`` or have 0 rows (then this is a pure row gather); ``order``: int64 row
+    numbers.  Host-only: needs the library, not a GPU."""
     lib = load()
     X = np.ascontiguousarray(X)
     if X.dtype not in (np.float32, np.float64):
         X = X.astype(np.float64)
-    synth = np.ascontiguousarray(synth, dtype=np.float32)
     n, d = X.shape
+    synth_dtype = np.dtype(synth_dtype)
+    if synth_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise ValueError("synthetic rows must be fp32 or fp64")
+    synth = np.empty((0, d), dtype=synth_dtype) if synth is None else np.ascontiguousarray(synth, dtype=synth_dtype)
     m = synth.shape[0]
     if m and synth.shape[1] != d:
         raise ValueError("synthetic rows have %d columns, X has %d" % (synth.shape[1], d))
@@ -187,11 +194,70 @@ def assemble_rows(X, synth, order, n_threads=None):
     out = np.empty((n_out, d), dtype=np.float64)
     if n_threads is None:
         n_threads = max(1, min(16, os.cpu_count() or 1))
-    rc = lib.smrt_assemble_rows(X.ctypes.data, int(X.dtype == np.float32), n, d, d, synth.ctypes.data if m else None, m, d,
-                                order.ctypes.data if order is not None else None, n_out, out.ctypes.data, int(n_threads))
+    fn = lib.smrt_assemble_rows if synth_dtype == np.float32 else lib.smrt_assemble_rows_f64
+    rc = fn(X.ctypes.data, int(X.dtype == np.float32), n, d, d, synth.ctypes.data if m else None, m, d,
+            order.ctypes.data if order is not None else None, n_out, out.ctypes.data, int(n_threads))
     if rc != 0:
         raise HipLibraryError("smrt_assemble_rows rejected its arguments (%d)" % rc)
     return out
+
+
+def _dev_f64(a, device):
+    """Host array or device tensor -> contiguous fp64 [n, d] tensor on ``device``."""
+    torch = _torch()
+    if hasattr(a, "data_ptr"):
+        t = a.to(device=device, dtype=torch.float64).contiguous()
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+    if t.dim() != 2:
+        raise ValueError("expected a 2-d matrix")
+    return t
+
+
+def knn_f64(C_rows, k, Q_rows=None, device=0, return_distance=False, to_host=True):
+    """The ``k`` rows of ``C_rows`` nearest (Euclidean, exact fp64, ties to the lower row) to each row of ``Q_rows``
+    (default: ``C_rows`` itself, so column 0 is the row itself unless it has an exact duplicate).
+
+    Returns int64 ``[nq, k]`` indices, preceded by the fp64 distances when ``return_distance``."""
+    torch = _torch()
+    dev = torch.device("cuda", int(device))
+    Ct = _dev_f64(C_rows, dev)
+    Qt = Ct if Q_rows is None else _dev_f64(Q_rows, dev)
+    if Qt.shape[1] != Ct.shape[1]:
+        raise ValueError("query rows have %d columns, fitted rows have %d" % (Qt.shape[1], Ct.shape[1]))
+    nq, nc, d = Qt.shape[0], Ct.shape[0], Ct.shape[1]
+    idx = torch.empty((nq, int(k)), dtype=torch.int64, device=dev)
+    rd = torch.empty((nq, int(k)), dtype=torch.float64, device=dev) if return_distance else None
+    stream = torch.cuda.current_stream(dev)
+    _check(load().smrt_knn_f64(Qt.data_ptr(), nq, Qt.stride(0), Ct.data_ptr(), nc, Ct.stride(0), d, int(k), idx.data_ptr(),
+                               rd.data_ptr() if rd is not None else None, C.c_void_p(stream.cuda_stream)), "smrt_knn_f64")
+    if return_distance:
+        rd = torch.sqrt(rd)                                  # the kernel ranks on squared distances
+        return (rd.cpu().numpy(), idx.cpu().numpy()) if to_host else (rd, idx)
+    return idx.cpu().numpy() if to_host else idx
+
+
+def smote_rows(X_dev, base_idx, nbr_idx, r, mode="perturb", to_host=True):
+    """Synthetic SMOTE rows from device-resident fp64 ``X_dev``: ``(x_b - x_n) * r + x_b`` or the midpoint."""
+    torch = _torch()
+    dev = X_dev.device
+    base = torch.from_numpy(np.ascontiguousarray(base_idx, dtype=np.int64)).to(dev)
+    nbr = torch.from_numpy(np.ascontiguousarray(nbr_idx, dtype=np.int64)).to(dev)
+    n = base.shape[0]
+    if nbr.shape[0] != n:
+        raise ValueError("base and neighbour index vectors differ in length")
+    rt = None
+    if mode == "perturb":
+        rt = torch.from_numpy(np.ascontiguousarray(r, dtype=np.float64)).to(dev)
+        if rt.shape[0] != n:
+            raise ValueError("one random factor per synthetic row is required")
+    out = torch.empty((n, X_dev.shape[1]), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    _check(load().smrt_smote_rows_f64(X_dev.data_ptr(), X_dev.shape[0], X_dev.stride(0), X_dev.shape[1], base.data_ptr(),
+                                      nbr.data_ptr(), rt.data_ptr() if rt is not None else None, n,
+                                      0 if mode == "perturb" else 1, out.data_ptr(), out.stride(0),
+                                      C.c_void_p(stream.cuda_stream)), "smrt_smote_rows_f64")
+    return out.cpu().numpy() if to_host else out
 
 
 class VaeHandle(object):

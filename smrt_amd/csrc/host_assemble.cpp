@@ -23,22 +23,21 @@ inline void put_row<double>(const double* src, double* dst, int64_t d) {
     std::memcpy(dst, src, sizeof(double) * (size_t)d);
 }
 
-template <class SRC>
-void assemble_range(const SRC* X, int64_t n_orig, int64_t d, int64_t ldx, const float* synth, int64_t ld_synth,
+template <class SRC, class SYN>
+void assemble_range(const SRC* X, int64_t n_orig, int64_t d, int64_t ldx, const SYN* synth, int64_t ld_synth,
                     const int64_t* order, int64_t lo, int64_t hi, double* out) {
     for (int64_t i = lo; i < hi; ++i) {
         const int64_t r = order ? order[i] : i;
         double* dst = out + i * d;
         if (r < n_orig) put_row<SRC>(X + r * ldx, dst, d);
-        else            put_row<float>(synth + (r - n_orig) * ld_synth, dst, d);
+        else            put_row<SYN>(synth + (r - n_orig) * ld_synth, dst, d);
     }
 }
 
-}  // namespace
-
-extern "C" int smrt_assemble_rows(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,
-                                  const float* synth, int64_t n_synth, int64_t ld_synth,
-                                  const int64_t* order, int64_t n_out, double* out, int32_t n_threads) {
+template <class SYN>
+int assemble(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,
+             const SYN* synth, int64_t n_synth, int64_t ld_synth,
+             const int64_t* order, int64_t n_out, double* out, int32_t n_threads) {
     if ((!X && n_orig > 0) || (!synth && n_synth > 0) || !out) return -1;
     if (n_orig < 0 || n_synth < 0 || d < 1 || ldx < d || (n_synth > 0 && ld_synth < d) || n_out < 0) return -1;
     if (!order && n_out != n_orig + n_synth) return -1;
@@ -48,8 +47,8 @@ extern "C" int smrt_assemble_rows(const void* X, int32_t x_is_f32, int64_t n_ori
     const int64_t min_rows = 4096;                                        // below this a thread is not worth starting
     int nt = std::max(1, (int)std::min<int64_t>(n_threads, (n_out + min_rows - 1) / min_rows));
     auto run = [&](int64_t lo, int64_t hi) {
-        if (x_is_f32) assemble_range<float>((const float*)X, n_orig, d, ldx, synth, ld_synth, order, lo, hi, out);
-        else          assemble_range<double>((const double*)X, n_orig, d, ldx, synth, ld_synth, order, lo, hi, out);
+        if (x_is_f32) assemble_range<float, SYN>((const float*)X, n_orig, d, ldx, synth, ld_synth, order, lo, hi, out);
+        else          assemble_range<double, SYN>((const double*)X, n_orig, d, ldx, synth, ld_synth, order, lo, hi, out);
     };
     if (nt == 1) { run(0, n_out); return 0; }
     std::vector<std::thread> pool;
@@ -60,4 +59,20 @@ extern "C" int smrt_assemble_rows(const void* X, int32_t x_is_f32, int64_t n_ori
     }
     for (auto& th : pool) th.join();
     return 0;
+}
+
+}  // namespace
+
+extern "C" int smrt_assemble_rows(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,
+                                  const float* synth, int64_t n_synth, int64_t ld_synth,
+                                  const int64_t* order, int64_t n_out, double* out, int32_t n_threads) {
+    return assemble<float>(X, x_is_f32, n_orig, d, ldx, synth, n_synth, ld_synth, order, n_out, out, n_threads);
+}
+
+// Same pass with fp64 appended rows: smote_balance (smote.py:93,254-260), and -- with no appended rows at all -- the
+// pure row gathers of over_sample_balance (over.py:77-81) and under_sample_balance (under.py:69-78).
+extern "C" int smrt_assemble_rows_f64(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,
+                                      const double* synth, int64_t n_synth, int64_t ld_synth,
+                                      const int64_t* order, int64_t n_out, double* out, int32_t n_threads) {
+    return assemble<double>(X, x_is_f32, n_orig, d, ldx, synth, n_synth, ld_synth, order, n_out, out, n_threads);
 }
