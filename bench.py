@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-balance", action="store_true", help="skip the end-to-end smrt_balance wall-clock leg")
+    ap.add_argument("--no-diag", action="store_true", help="skip the measured-peak / latency-floor kernels (rocprof runs)")
     args = ap.parse_args()
 
     import torch
@@ -246,7 +247,7 @@ def main():
             "kernel_launches_per_step": sess.last_epoch_launches,
             "final_cost": float(costs[-1]),
         }
-        if world == 1:
+        if world == 1 and not args.no_diag:
             # What the device itself allows: the fp32 MFMA rate a register-resident loop reaches, and the
             # cost of the same launch pattern with no arithmetic in it (a captured chain of dependent 8-workgroup kernels).
             k_per_mb = max(1, sess.last_epoch_launches // steps_per_epoch)

@@ -170,6 +170,46 @@ def case_balance_c3(name, threads):
             "wall_s_median": float(np.median(times)), "wall_s_all": times}
 
 
+def case_smote(name, which):
+    """smote_balance end to end on the C1 / C2 inputs, next to sklearn's kd-tree search alone on the host (the
+    dominant cost of the reference's smote_balance, smote.py:63-69) and the kernel's own time and fp64 rate."""
+    import torch
+    from sklearn.neighbors import NearestNeighbors
+    from smrt_amd import _hip
+    from smrt_amd.balance import smote_balance
+    if which == "C1":
+        X, y = mnist_shaped(5444, 500)
+        kw = dict(balance_ratio=0.5, n_neighbors=10, random_state=42, shuffle=False)
+    else:
+        X, y = tabular(1000000, 64, 19608)
+        X = X.astype(np.float64)
+        kw = dict(balance_ratio=0.2, n_neighbors=5, random_state=42)
+    smote_balance(X[:3000], (np.arange(3000) % 30 == 0).astype(int), **kw)                  # warm-up
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        Xb, yb = smote_balance(X, y, **kw)
+        times.append(time.perf_counter() - t0)
+    X_sub = np.ascontiguousarray(X[y == 1], dtype=np.float64)
+    k = kw["n_neighbors"] + 1
+    Xd = torch.from_numpy(X_sub).cuda()
+    _hip.knn_f64(Xd, k, to_host=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        idx = _hip.knn_f64(Xd, k, to_host=False)
+    torch.cuda.synchronize()
+    knn_s = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    ref = NearestNeighbors(n_neighbors=k, algorithm="kd_tree").fit(X_sub).kneighbors(X_sub, return_distance=False)
+    cpu_s = time.perf_counter() - t0
+    n, d = X_sub.shape
+    return {"case": name, "config": which, "in_rows": int(len(y)), "out_rows": int(len(yb)), "minority_rows": int(n),
+            "wall_s_median": float(np.median(times)), "wall_s_all": times, "knn_kernel_ms": 1e3 * knn_s,
+            "knn_fp64_tflops": 3.0 * n * n * d / knn_s / 1e12, "cpu_kdtree_search_s": cpu_s, "cpu_cores": 1,
+            "neighbours_equal_sklearn": bool(np.array_equal(idx.cpu().numpy(), ref))}
+
+
 CASES = {
     "train_n2_b128": lambda: case_train("train_n2_b128", "N2", 19608, 128, "rms_prop", 10),
     "train_n2_b4096": lambda: case_train("train_n2_b4096", "N2", 19608, 4096, "rms_prop", 20),
@@ -182,6 +222,8 @@ CASES = {
     "gen_n5": lambda: case_gen("gen_n5", "N5", 1000000, reps=3),
     "balance_c1": lambda: case_balance("balance_c1", "C1"),
     "balance_c2": lambda: case_balance("balance_c2", "C2"),
+    "smote_c1": lambda: case_smote("smote_c1", "C1"),
+    "smote_c2": lambda: case_smote("smote_c2", "C2"),
     "balance_c3_seq": lambda: case_balance_c3("balance_c3_seq", 1),
     "balance_c3_par": lambda: case_balance_c3("balance_c3_par", 8),
 }
