@@ -408,7 +408,16 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
         wd[r] = a.has_drop ? a.Wd[idx[r]] : w[r];
         mk[r] = a.has_drop ? a.mask[idx[r]] : 1.f;
     }
-    const float b1pow = a.st->b1pow, b2pow = a.st->b2pow;     // used in the epilogue only (Adam)
+    // Step-dependent scalars.  Only Adam reads them here (its bias-correction powers), so only Adam has to wait for
+    // every workgroup before advancing them (ticket below: a device-scope atomic round trip at the tail of the launch).
+    // Any other optimizer lets workgroup 0 advance them right away, off the critical path.
+    const bool adam = a.opt == 2;
+    const float b1pow = adam ? a.st->b1pow : 0.f, b2pow = adam ? a.st->b2pow : 0.f;
+    if (!adam && blockIdx.x == 0 && tid == 0) {
+        a.st->step += 1;
+        a.st->b1pow *= 0.9f;
+        a.st->b2pow *= 0.999f;
+    }
 
     BST(21);
     // ---- [X | 1]^T . dPre over all rows.  Both operands are stored blocked transposed ([row block][feature][16 rows])
@@ -493,13 +502,15 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
     const float tot = block_sum_256(l2acc, red);            // __syncthreads inside: every lane's st reads are done
     if (tid == 0) {
         a.l2_partials[blockIdx.x] = tot;
-        // last workgroup out advances the step-dependent scalars: every other workgroup has already read them
-        const unsigned prev = atomicAdd(a.ticket, 1u);
-        if (prev == gridDim.x - 1) {
-            a.st->step += 1;
-            a.st->b1pow *= 0.9f;
-            a.st->b2pow *= 0.999f;
-            *a.ticket = 0u;
+        if (adam) {
+            // last workgroup out advances the step-dependent scalars: every other workgroup has already read them
+            const unsigned prev = atomicAdd(a.ticket, 1u);
+            if (prev == gridDim.x - 1) {
+                a.st->step += 1;
+                a.st->b1pow *= 0.9f;
+                a.st->b2pow *= 0.999f;
+                *a.ticket = 0u;
+            }
         }
     }
     BST(24);
