@@ -41,6 +41,23 @@ def test_small_batch_to_tiled_kernel_boundary(rows):
     h.close()
 
 
+@pytest.mark.parametrize("rows,D,hid", [(3000, 1024, 1000), (6200, 1000, 520)])
+def test_three_tile_shapes_of_the_tiled_gemm(rows, D, hid):
+    """The LDS-tiled GEMM picks 128x128, 128x64 or 64x64 tiles by grid size (vae_kernels.hip: tile_sel).  These two
+    shapes put the wide layers (forward, output + BCE, backward) on the 128x64 tiles (24 x 8 = 192 and 49 x 5 = 245
+    tiles of 128x128) with ragged edges in both dimensions, the narrow heads on 64x64; one step against the oracle."""
+    rs = np.random.RandomState(rows)
+    Z = 9
+    o, h = _pair(D, [hid], Z, "sigmoid", "rms_prop", rows, rs)
+    X, eps = rs.uniform(0, 1, size=(rows, D)), rs.normal(size=(rows, Z))
+    c_o, (gW, gb) = o.train_step(X, eps, return_grads=True)
+    c_h, g_h = h.train_step(X, eps, want_grads=True)
+    assert np.isclose(c_h, c_o, rtol=1e-4), (c_h, c_o)
+    _close(g_h, np.concatenate([np.concatenate([w.ravel(), b.ravel()]) for w, b in zip(gW, gb)]), "gradients")
+    _close(h.get_params(), flatten_params(o.params), "params")
+    h.close()
+
+
 def test_six_hidden_layers_single_latent_batch_of_one():
     """SMRT_MAX_HIDDEN layers, Z = 1, widths that are multiples of nothing, batches of 1 / 2 / 33 rows."""
     rs = np.random.RandomState(12)

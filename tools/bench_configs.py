@@ -215,6 +215,7 @@ CASES = {
     "train_n2_b4096": lambda: case_train("train_n2_b4096", "N2", 19608, 4096, "rms_prop", 20),
     "train_n1_b128": lambda: case_train("train_n1_b128", "N1", 5000, 128, "rms_prop", 20),
     "train_n1_b256": lambda: case_train("train_n1_b256", "N1", 500, 256, "rms_prop", 50),
+    "train_n1_b4096": lambda: case_train("train_n1_b4096", "N1", 20000, 4096, "adam", 10),
     "train_n1_b65536": lambda: case_train("train_n1_b65536", "N1", 262144, 65536, "adam", 3),
     "train_n5_b4096": lambda: case_train("train_n5_b4096", "N5", 19608, 4096, "adam", 5),
     "train_n5_b65536": lambda: case_train("train_n5_b65536", "N5", 131072, 65536, "adam", 2),
