@@ -18,46 +18,72 @@ extern int smrt_set_error(int code, const std::string& m);
 namespace {
 
 constexpr int TQ = 64, TC = 64, DK = 16, KNN_THREADS = 256, KNN_KMAX = 64;
+constexpr int SLAB = TQ + 1;            // LDS row pitch of a staged slab (doubles): odd, so the transposing store is conflict-free
 
-// LDS: qs[DK][TQ] cs[DK][TC] | dist[TQ][TC+1] | topd[TQ][k] | topi[TQ][k]
+// LDS: qs[DK][SLAB] cs[DK][SLAB] | dist[TQ][TC+1] | topd[TQ][k] | topi[TQ][k]
 __global__ void __launch_bounds__(KNN_THREADS)
 knn_kernel(const double* __restrict__ Q, long nq, long ldq, const double* __restrict__ Cm, long nc, long ldc, int d, int k,
            long long* __restrict__ idx_out, double* __restrict__ dist_out) {
     extern __shared__ double lds[];
+    __shared__ unsigned flags[KNN_THREADS];
     double* qs = lds;
-    double* cs = qs + DK * TQ;
-    double* dist = cs + DK * TC;
+    double* cs = qs + DK * SLAB;
+    double* dist = cs + DK * SLAB;
     double* topd = dist + TQ * (TC + 1);
     long long* topi = reinterpret_cast<long long*>(topd + TQ * k);
 
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;             // thread owns queries 4*ty.., candidates 4*tx..
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;             // thread owns queries 4 ty + a, candidates tx + 16 b
+                                                                     // (16 lanes read 16 consecutive doubles: no bank conflict)
     const long q0 = (long)blockIdx.x * TQ;
 
     for (int i = t; i < TQ * k; i += KNN_THREADS) { topd[i] = __builtin_inf(); topi[i] = -1; }
 
-    for (long c0 = 0; c0 < nc; c0 += TC) {
+    // Global -> LDS staging is software-pipelined: the slab of stage s + 1 (the next 16 features, or the first 16 of the
+    // next candidate tile) is requested into registers right after the barrier that publishes stage s, and lands while
+    // stage s is being multiplied.  Each thread carries 4 + 4 doubles; element e = t + 256 u is row e / 16, feature e % 16.
+    const int nd = (d + DK - 1) / DK;
+    const long n_ct = (nc + TC - 1) / TC;
+    double pq[4], pc[4];
+    auto fetch = [&](long ct, int js) {
+        const long c0f = ct * TC;
+        const int j0f = js * DK;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = t + KNN_THREADS * u;
+            const int r = e / DK, j = e % DK;
+            const long qr = q0 + r, cr = c0f + r;
+            const bool jv = j0f + j < d;
+            pq[u] = (jv && qr < nq) ? Q[qr * ldq + j0f + j] : 0.0;
+            pc[u] = (jv && cr < nc) ? Cm[cr * ldc + j0f + j] : 0.0;
+        }
+    };
+    fetch(0, 0);
+    for (long ct = 0; ct < n_ct; ++ct) {
+        const long c0 = ct * TC;
         double acc[4][4];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
 
-        for (int j0 = 0; j0 < d; j0 += DK) {
-            __syncthreads();
-            // stage a [64 rows x DK features] slab of each operand, transposed to [feature][row]
-            for (int e = t; e < TQ * DK; e += KNN_THREADS) {
+        for (int js = 0; js < nd; ++js) {
+            const int j0 = js * DK;
+            __syncthreads();                                   // the previous stage's readers are done
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                      // registers -> LDS, transposed to [feature][row]
+                const int e = t + KNN_THREADS * u;
                 const int r = e / DK, j = e % DK;
-                const long qr = q0 + r, cr = c0 + r;
-                const bool jv = j0 + j < d;
-                qs[j * TQ + r] = (jv && qr < nq) ? Q[qr * ldq + j0 + j] : 0.0;
-                cs[j * TC + r] = (jv && cr < nc) ? Cm[cr * ldc + j0 + j] : 0.0;
+                qs[j * SLAB + r] = pq[u];
+                cs[j * SLAB + r] = pc[u];
             }
             __syncthreads();
+            if (js + 1 < nd) fetch(ct, js + 1);
+            else if (ct + 1 < n_ct) fetch(ct + 1, 0);
             const int jn = min(DK, d - j0);
-            for (int j = 0; j < jn; ++j) {
+            auto feature = [&](int j) {
                 double qa[4], cb[4];
 #pragma unroll
-                for (int a = 0; a < 4; ++a) { qa[a] = qs[j * TQ + 4 * ty + a]; cb[a] = cs[j * TC + 4 * tx + a]; }
+                for (int a = 0; a < 4; ++a) { qa[a] = qs[j * SLAB + 4 * ty + a]; cb[a] = cs[j * SLAB + tx + 16 * a]; }
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -65,25 +91,55 @@ knn_kernel(const double* __restrict__ Q, long nq, long ldq, const double* __rest
                         const double diff = qa[a] - cb[b];
                         acc[a][b] = acc[a][b] + diff * diff;         // not contracted: -ffp-contract=off
                     }
+            };
+            if (jn == DK) {
+                // whole slab: straight-line, so the LDS reads of later features are in flight under the arithmetic of
+                // earlier ones (feature order of every sum is unchanged)
+#pragma unroll
+                for (int j = 0; j < DK; ++j) feature(j);
+            } else {
+                for (int j = 0; j < jn; ++j) feature(j);
             }
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) dist[(4 * ty + a) * (TC + 1) + 4 * tx + b] = acc[a][b];
+            for (int b = 0; b < 4; ++b) dist[(4 * ty + a) * (TC + 1) + tx + 16 * b] = acc[a][b];
+        __syncthreads();
+        // Selection.  After the first few tiles almost nothing beats a query's current k-th distance, so all 256 threads
+        // first screen the tile (4 threads per query, 16 candidates each, loads batched) against that bound and leave a
+        // bit mask; only then does the query's owner insert the few survivors, in candidate order, re-checking each
+        // against the bound as it tightens (strict <: on a tie the earlier row stays ahead).
+        {
+            const int qi = t >> 2, part = t & 3;
+            const double bound = topd[qi * k + k - 1];
+            const double* dp = dist + qi * (TC + 1) + part * 16;
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = dp[u];
+            unsigned m = 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) m |= (v[u] < bound ? 1u : 0u) << u;
+            flags[t] = m;
+        }
         __syncthreads();
         if (t < TQ && q0 + t < nq) {
             double* td = topd + t * k;
             long long* ti = topi + t * k;
             const int cn = (int)min((long)TC, nc - c0);
             double worst = td[k - 1];
-            for (int c = 0; c < cn; ++c) {
-                const double v = dist[t * (TC + 1) + c];
-                if (v < worst) {                                      // strict: on a tie the earlier row stays ahead
-                    int p = k - 1;
-                    while (p > 0 && td[p - 1] > v) { td[p] = td[p - 1]; ti[p] = ti[p - 1]; --p; }
-                    td[p] = v; ti[p] = c0 + c;
-                    worst = td[k - 1];
+            for (int part = 0; part < 4; ++part) {
+                unsigned m = flags[4 * t + part];
+                while (m) {
+                    const int c = part * 16 + __builtin_ctz(m);
+                    m &= m - 1;
+                    const double v = dist[t * (TC + 1) + c];
+                    if (c < cn && v < worst) {
+                        int p = k - 1;
+                        while (p > 0 && td[p - 1] > v) { td[p] = td[p - 1]; ti[p] = ti[p - 1]; --p; }
+                        td[p] = v; ti[p] = c0 + c;
+                        worst = td[k - 1];
+                    }
                 }
             }
         }
@@ -133,9 +189,9 @@ extern "C" int smrt_knn_f64(const double* Q_dev, int64_t nq, int64_t ldq, const 
         return smrt_set_error(-1, "smrt_knn_f64: bad sizes");
     if (k < 1 || k > KNN_KMAX || k > nc) return smrt_set_error(-1, "smrt_knn_f64: k must be in [1, min(64, candidates)]");
     if ((nq + TQ - 1) / TQ > 0x7fffffffL) return smrt_set_error(-1, "smrt_knn_f64: too many query rows");
-    const size_t lds_bytes = sizeof(double) * ((size_t)DK * TQ + (size_t)DK * TC + (size_t)TQ * (TC + 1) + 2 * (size_t)TQ * k);
+    const size_t lds_bytes = sizeof(double) * (2 * (size_t)DK * SLAB + (size_t)TQ * (TC + 1) + 2 * (size_t)TQ * k);
     // always the same value (the size at k = 64), so concurrent callers with different k cannot undercut each other
-    constexpr size_t lds_max = sizeof(double) * ((size_t)DK * TQ + (size_t)DK * TC + (size_t)TQ * (TC + 1) + 2 * (size_t)TQ * KNN_KMAX);
+    constexpr size_t lds_max = sizeof(double) * (2 * (size_t)DK * SLAB + (size_t)TQ * (TC + 1) + 2 * (size_t)TQ * KNN_KMAX);
     KNNC(hipFuncSetAttribute((const void*)knn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     hipLaunchKernelGGL(knn_kernel, dim3((unsigned)((nq + TQ - 1) / TQ)), dim3(KNN_THREADS), lds_bytes, (hipStream_t)hip_stream,
                        Q_dev, (long)nq, (long)ldq, C_dev, (long)nc, (long)ldc, (int)d, (int)k,
