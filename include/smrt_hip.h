@@ -156,6 +156,13 @@ int  smrt_assemble_rows(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t
                         const float* synth, int64_t n_synth, int64_t ld_synth,
                         const int64_t* order, int64_t n_out, double* out, int32_t n_threads);
 
+/* The same pass in two halves (no counterpart in the reference): which = 1 writes only the output rows whose source is X
+ * (synth may be NULL; smrt_balance runs this while the GPU still trains), which = 2 only those whose source is a
+ * synthetic row (X may be NULL), 0 everything.  Rows of the other kind are left untouched. */
+int  smrt_assemble_rows_part(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,
+                             const float* synth, int64_t n_synth, int64_t ld_synth,
+                             const int64_t* order, int64_t n_out, double* out, int32_t n_threads, int32_t which);
+
 /* Same pass with fp64 appended rows (smote_balance, smrt/balance/smote.py:93,254-260); with n_synth == 0 it is the row
  * gather of over_sample_balance (over.py:77-81) and under_sample_balance (under.py:69-78). */
 int  smrt_assemble_rows_f64(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,

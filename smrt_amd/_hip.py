@@ -27,7 +27,7 @@ EXPORTS = [
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
-    "smrt_assemble_rows", "smrt_assemble_rows_f64", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
+    "smrt_assemble_rows", "smrt_assemble_rows_part", "smrt_assemble_rows_f64", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
     "smrt_last_error", "smrt_version",
 ]
 
@@ -99,6 +99,7 @@ def load():
     lib.smrt_vae_profile_epochs.argtypes = [vp, vp, i64, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(i64)]
     lib.smrt_assemble_rows.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32]
     lib.smrt_assemble_rows_f64.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32]
+    lib.smrt_assemble_rows_part.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32, i32]
     _lib = lib
     return lib
 
@@ -200,6 +201,44 @@ def assemble_rows(X, synth, order, n_threads=None, synth_dtype=np.float32):
     if rc != 0:
         raise HipLibraryError("smrt_assemble_rows rejected its arguments (%d)" % rc)
     return out
+
+
+class SplitAssembly(object):
+    """``assemble_rows`` in two halves over one preallocated fp64 output: ``originals()`` writes the rows whose source is
+    ``X`` (callable while the synthetic rows are still being made), ``synthetic(synth)`` the rest; ``out`` is complete
+    after both.  ``n_synth`` fp32 synthetic rows are expected; ``order`` as in ``assemble_rows``."""
+
+    def __init__(self, X, n_synth, order, n_threads=None):
+        self._lib = load()
+        X = np.ascontiguousarray(X)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        self.X, self.n_synth = X, int(n_synth)
+        self.order = None if order is None else np.ascontiguousarray(order, dtype=np.int64)
+        n, d = X.shape
+        self.n_out = n + self.n_synth if self.order is None else self.order.shape[0]
+        self.out = np.empty((self.n_out, d), dtype=np.float64)
+        self.n_threads = int(n_threads) if n_threads else max(1, min(16, os.cpu_count() or 1))
+
+    def _run(self, synth, which):
+        n, d = self.X.shape
+        rc = self._lib.smrt_assemble_rows_part(
+            self.X.ctypes.data, int(self.X.dtype == np.float32), n, d, d, synth.ctypes.data if synth is not None else None,
+            self.n_synth, d, self.order.ctypes.data if self.order is not None else None, self.n_out, self.out.ctypes.data,
+            self.n_threads, which)
+        if rc != 0:
+            raise HipLibraryError("smrt_assemble_rows_part rejected its arguments (%d)" % rc)
+
+    def originals(self):
+        self._run(None, 1)
+
+    def synthetic(self, synth):
+        synth = np.ascontiguousarray(synth, dtype=np.float32)
+        if synth.shape != (self.n_synth, self.X.shape[1]):
+            raise ValueError("expected %r synthetic rows, got %r" % ((self.n_synth, self.X.shape[1]), synth.shape))
+        if self.n_synth:
+            self._run(synth, 2)
+        return self.out
 
 
 def _dev_f64(a, device):

@@ -209,6 +209,10 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
             cursor += need
         output_order = random_state.permutation(np.arange(n_total)) if shuffle else None
         lap("draws")
+        # the rows that come from X are written now, while the GPU is still training (85 % of the output on C2)
+        assembly = _hip.SplitAssembly(X, n_synth, output_order)
+        assembly.originals()
+        lap("originals")
 
         # ---- per-class generate for the fresh fits: decode what was drawn above
         for j, (code, label, n_sub, need) in enumerate(jobs):
@@ -241,7 +245,7 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
 
     if shuffle:
         y_out = y_out[output_order]
-    X_out = _hip.assemble_rows(X, synth, output_order)    # fp64 [X ; synthetic][order] in one pass
+    X_out = assembly.synthetic(synth)                     # the other rows of fp64 [X ; synthetic][order]
     lap("assemble")
 
     if return_estimators:

@@ -241,7 +241,8 @@ static void plan_fused(smrt_vae* h) {
 }
 
 // Zero-fills go on the handle's stream and are waited for there: a device-wide synchronise is refused by the runtime
-// while ANY stream of the process is being captured, and other host threads capture their own handles' epochs.
+// while ANY stream of the process is being captured (a caller's own graph capture, for instance), and several host
+// threads drive handles at the same time.
 template <class T> static int dalloc(T** p, size_t n_elems, hipStream_t s) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
     if (n_elems == 0) return 0;
@@ -772,7 +773,7 @@ int smrt_vae_set_dropout_masks(smrt_vae* h, const float* host_flat, int64_t n) {
 }
 
 // cost_dev is two floats for the handle's lifetime (slot 0: the cost that is read back, slot 1: scratch for
-// steps whose cost nobody reads) so captured graphs never hold a stale pointer; only the pinned mirror grows.
+// steps whose cost nobody reads) so epoch graphs never hold a stale pointer; only the pinned mirror grows.
 static int ensure_cost(smrt_vae* h, long n) {
     if (n > h->cost_pin_cap) {
         if (h->cost_pin) (void)hipHostFree(h->cost_pin);
@@ -840,7 +841,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
         return 0;
     };
 
-    // A captured graph replays the identical epoch: every step-dependent scalar (Philox step, Adam powers)
+    // The epoch graph replays the identical epoch: every step-dependent scalar (Philox step, Adam powers)
     // lives in device memory, so only the cost slot differs -> the graph writes slot 0 and a copy node moves it.
     bool graphed = false;
     if (h->use_graph && !h->prof && n_epochs > 1 && h->stream == h->own_stream) {
@@ -868,7 +869,6 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
         }
     }
     int done = 0; float last_cost = 0.f; bool have_last = false; int rc = 0;
-    auto cleanup = [&]() {};
     auto run_epoch = [&](int ep) -> int {
         HIPC(hipEventRecord(h->events[2 * ep], h->stream));
         if (graphed) HIPC(hipGraphLaunch(h->gexec, h->stream));
@@ -879,16 +879,16 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     };
     if (!early_stopping) {
         for (int ep = 0; ep < n_epochs && rc == 0; ++ep) rc = run_epoch(ep);
-        if (rc) { cleanup(); return rc; }
+        if (rc) return rc;
         hipError_t e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) { cleanup(); return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e));
         done = n_epochs;
     } else {
         for (int ep = 0; ep < n_epochs; ++ep) {
             rc = run_epoch(ep);
-            if (rc) { cleanup(); return rc; }
+            if (rc) return rc;
             hipError_t e = hipStreamSynchronize(h->stream);
-            if (e != hipSuccess) { cleanup(); return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e)); }
+            if (e != hipSuccess) return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e));
             done = ep + 1;
             const float c = h->cost_pin[ep];
             if (!have_last) { last_cost = c; have_last = true; }
@@ -904,7 +904,6 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     }
     h->steps += (int64_t)done * nb;
     if (epochs_done) *epochs_done = done;
-    cleanup();
     return 0;
 }
 

@@ -25,20 +25,21 @@ inline void put_row<double>(const double* src, double* dst, int64_t d) {
 
 template <class SRC, class SYN>
 void assemble_range(const SRC* X, int64_t n_orig, int64_t d, int64_t ldx, const SYN* synth, int64_t ld_synth,
-                    const int64_t* order, int64_t lo, int64_t hi, double* out) {
+                    const int64_t* order, int64_t lo, int64_t hi, double* out, int which) {
     for (int64_t i = lo; i < hi; ++i) {
         const int64_t r = order ? order[i] : i;
         double* dst = out + i * d;
-        if (r < n_orig) put_row<SRC>(X + r * ldx, dst, d);
-        else            put_row<SYN>(synth + (r - n_orig) * ld_synth, dst, d);
+        if (r < n_orig) { if (which != 2) put_row<SRC>(X + r * ldx, dst, d); }
+        else            { if (which != 1) put_row<SYN>(synth + (r - n_orig) * ld_synth, dst, d); }
     }
 }
 
 template <class SYN>
 int assemble(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,
              const SYN* synth, int64_t n_synth, int64_t ld_synth,
-             const int64_t* order, int64_t n_out, double* out, int32_t n_threads) {
-    if ((!X && n_orig > 0) || (!synth && n_synth > 0) || !out) return -1;
+             const int64_t* order, int64_t n_out, double* out, int32_t n_threads, int which = 0) {
+    if (which < 0 || which > 2) return -1;
+    if ((!X && n_orig > 0 && which != 2) || (!synth && n_synth > 0 && which != 1) || !out) return -1;
     if (n_orig < 0 || n_synth < 0 || d < 1 || ldx < d || (n_synth > 0 && ld_synth < d) || n_out < 0) return -1;
     if (!order && n_out != n_orig + n_synth) return -1;
     if (order)
@@ -47,8 +48,8 @@ int assemble(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t
     const int64_t min_rows = 4096;                                        // below this a thread is not worth starting
     int nt = std::max(1, (int)std::min<int64_t>(n_threads, (n_out + min_rows - 1) / min_rows));
     auto run = [&](int64_t lo, int64_t hi) {
-        if (x_is_f32) assemble_range<float, SYN>((const float*)X, n_orig, d, ldx, synth, ld_synth, order, lo, hi, out);
-        else          assemble_range<double, SYN>((const double*)X, n_orig, d, ldx, synth, ld_synth, order, lo, hi, out);
+        if (x_is_f32) assemble_range<float, SYN>((const float*)X, n_orig, d, ldx, synth, ld_synth, order, lo, hi, out, which);
+        else          assemble_range<double, SYN>((const double*)X, n_orig, d, ldx, synth, ld_synth, order, lo, hi, out, which);
     };
     if (nt == 1) { run(0, n_out); return 0; }
     std::vector<std::thread> pool;
@@ -75,4 +76,13 @@ extern "C" int smrt_assemble_rows_f64(const void* X, int32_t x_is_f32, int64_t n
                                       const double* synth, int64_t n_synth, int64_t ld_synth,
                                       const int64_t* order, int64_t n_out, double* out, int32_t n_threads) {
     return assemble<double>(X, x_is_f32, n_orig, d, ldx, synth, n_synth, ld_synth, order, n_out, out, n_threads);
+}
+
+// The same pass in two halves, so that the rows that come from X (85 % of the output on C2) are written while the GPU is
+// still training: which = 1 writes only the output rows whose source is X (synth may be NULL), which = 2 only those whose
+// source is a synthetic row (X may be NULL), 0 everything.  Rows of the other kind are left untouched.
+extern "C" int smrt_assemble_rows_part(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,
+                                       const float* synth, int64_t n_synth, int64_t ld_synth,
+                                       const int64_t* order, int64_t n_out, double* out, int32_t n_threads, int32_t which) {
+    return assemble<float>(X, x_is_f32, n_orig, d, ldx, synth, n_synth, ld_synth, order, n_out, out, n_threads, which);
 }

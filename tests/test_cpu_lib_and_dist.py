@@ -135,3 +135,15 @@ def test_assemble_rows_matches_numpy():
         _hip.assemble_rows(big, S[:, :3], np.array([0, 20037]))
     with pytest.raises(ValueError):
         _hip.assemble_rows(big, S, None)
+    # the two halves (rows from X first, synthetic rows later) add up to the one-pass result, and touch nothing else
+    for order_ in (order, None):
+        sa = _hip.SplitAssembly(big, 37, order_, n_threads=4)
+        sa.out[:] = -7.0
+        sa.originals()
+        ref = np.vstack([big.astype(np.float64), S[:, :3].astype(np.float64)])
+        ref = ref if order_ is None else ref[order_]
+        from_x = (np.arange(20037) if order_ is None else order_) < 20000
+        assert np.array_equal(sa.out[from_x], ref[from_x]) and np.all(sa.out[~from_x] == -7.0)
+        assert np.array_equal(sa.synthetic(S[:, :3]), ref)
+    with pytest.raises(ValueError):
+        _hip.SplitAssembly(big, 37, None).synthetic(S[:5, :3])
