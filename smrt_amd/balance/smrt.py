@@ -174,6 +174,7 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
             pool = ThreadPoolExecutor(max_workers=min(n_threads, n_fresh))
             fits = [None if f is None else pool.submit(f.fit, X_sub) for f, X_sub in zip(fits, subs)]
 
+        synth.fill(0.0)                      # touch the slab's pages while the fits run, not while they are waited for
         # ---- the shared stream, in class order (smrt.py:226-238 via autoencoder.py:519-572)
         for j, (code, label, n_sub, need) in enumerate(jobs):
             mine = owners[j] == rank
@@ -212,6 +213,9 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
         # the rows that come from X are written now, while the GPU is still training (85 % of the output on C2)
         assembly = _hip.SplitAssembly(X, n_synth, output_order)
         assembly.originals()
+        if not gen_from_samples:
+            # latent draws to the kernels' dtype (what feed_forward does, autoencoder.py:517), still under the cover of the fits
+            drawn = [(None if nz is None else nz.astype(np.float32), si) for nz, si in drawn]
         lap("originals")
 
         # ---- per-class generate for the fresh fits: decode what was drawn above
@@ -223,12 +227,13 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
             noise, sample_idcs = drawn[j]
             start = blocks[j][0]
             if not gen_from_samples:
-                synthetic = encoder.feed_forward(noise)                           # == generate(n=need, **generate_args)
+                # == generate(n=need, **generate_args); the decoded rows are downloaded straight into their slab
+                rows_dev = encoder.sess.decode(noise, to_host=False)
+                torch.from_numpy(synth[start:start + need]).copy_(rows_dev)
             else:
                 z_mu, log_sigma = encoder.encode(subs[j][sample_idcs, :])         # == generate_from_sample(...)
                 z_mu += noise * np.exp(log_sigma)
-                synthetic = encoder.feed_forward(z_mu)
-            synth[start:start + need] = np.asarray(synthetic)
+                synth[start:start + need] = np.asarray(encoder.feed_forward(z_mu))
             drawn[j] = None
     finally:
         if pool is not None:
