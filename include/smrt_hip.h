@@ -163,6 +163,11 @@ int  smrt_assemble_rows_part(const void* X, int32_t x_is_f32, int64_t n_orig, in
                              const float* synth, int64_t n_synth, int64_t ld_synth,
                              const int64_t* order, int64_t n_out, double* out, int32_t n_threads, int32_t which);
 
+/* The finiteness sweep of sklearn's check_array (smrt/balance/base.py:24) on n_threads cores: 1 when all n elements of
+ * the fp32 / fp64 HOST array are finite, 0 otherwise (the caller then lets sklearn raise its own error), -1 on a bad
+ * argument. */
+int  smrt_all_finite(const void* X, int32_t x_is_f32, int64_t n, int32_t n_threads);
+
 /* Same pass with fp64 appended rows (smote_balance, smrt/balance/smote.py:93,254-260); with n_synth == 0 it is the row
  * gather of over_sample_balance (over.py:77-81) and under_sample_balance (under.py:69-78). */
 int  smrt_assemble_rows_f64(const void* X, int32_t x_is_f32, int64_t n_orig, int64_t d, int64_t ldx,

@@ -27,7 +27,7 @@ EXPORTS = [
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
-    "smrt_assemble_rows", "smrt_assemble_rows_part", "smrt_assemble_rows_f64", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
+    "smrt_assemble_rows", "smrt_assemble_rows_part", "smrt_assemble_rows_f64", "smrt_all_finite", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
     "smrt_last_error", "smrt_version",
 ]
 
@@ -99,6 +99,7 @@ def load():
     lib.smrt_vae_profile_epochs.argtypes = [vp, vp, i64, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(i64)]
     lib.smrt_assemble_rows.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32]
     lib.smrt_assemble_rows_f64.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32]
+    lib.smrt_all_finite.argtypes = [vp, i32, i64, i32]
     lib.smrt_assemble_rows_part.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32, i32]
     _lib = lib
     return lib
@@ -201,6 +202,16 @@ def assemble_rows(X, synth, order, n_threads=None, synth_dtype=np.float32):
     if rc != 0:
         raise HipLibraryError("smrt_assemble_rows rejected its arguments (%d)" % rc)
     return out
+
+
+def all_finite(X, n_threads=None):
+    """True when the C-contiguous fp32 / fp64 host array ``X`` holds no NaN or infinity (multi-threaded sweep)."""
+    if n_threads is None:
+        n_threads = max(1, min(16, os.cpu_count() or 1))
+    rc = load().smrt_all_finite(X.ctypes.data, int(X.dtype == np.float32), X.size, int(n_threads))
+    if rc < 0:
+        raise HipLibraryError("smrt_all_finite rejected its arguments")
+    return rc == 1
 
 
 class SplitAssembly(object):

@@ -26,14 +26,32 @@ def validate_X_y_ratio_classes(X, y, ratio, copy=True, keep_float32=False):
     """
     validate_float(ratio, "balance_ratio")
     dtype = [np.float64, np.float32] if (keep_float32 and getattr(X, "dtype", None) == np.float32) else NPDTYPE
-    X = check_array(X, accept_sparse=False, dtype=dtype, ensure_2d=True, copy=copy, order="C")
+    # sklearn's finiteness sweep is one core's work (most of this function at 1M x 64); a C-contiguous float matrix is
+    # swept by the library on every core instead, and sklearn is only asked to look when there is something to report
+    fast = (isinstance(X, np.ndarray) and X.ndim == 2 and X.flags.c_contiguous and X.size >= (1 << 20)
+            and X.dtype in (np.float32, np.float64))
+    if fast:
+        from .. import _hip
+        fast = _hip.all_finite(X)
+    X = check_array(X, accept_sparse=False, dtype=dtype, ensure_2d=True, copy=copy, order="C",
+                    ensure_all_finite=not fast)
     y = column_or_1d(check_array(y, accept_sparse=False, ensure_2d=False, dtype=None), warn=False)
 
-    kind = type_of_target(y)
+    small_ints = y.dtype.kind in "iu" and y.size > 0 and int(y.min()) >= 0 and int(y.max()) < (1 << 16)
+    if small_ints:
+        # non-negative integer labels: one counting pass gives what type_of_target + np.unique (two sorts of y) give --
+        # integer targets are 'binary' with up to two distinct values and 'multiclass' beyond (sklearn.utils.multiclass)
+        tally = np.bincount(y)
+        present_classes = np.flatnonzero(tally).astype(y.dtype)
+        counts = tally[present_classes]
+        kind = "binary" if len(present_classes) <= 2 else "multiclass"
+    else:
+        kind = type_of_target(y)
     if kind not in ("binary", "multiclass"):
         raise ValueError("balancers only support (binary, multiclass) targets, but got %r" % kind)
 
-    present_classes, counts = np.unique(y, return_counts=True)
+    if not small_ints:
+        present_classes, counts = np.unique(y, return_counts=True)
     n_classes = len(present_classes)
     if n_classes > MAX_N_CLASSES:
         raise ValueError("balancers currently only support a maximum of %i unique class labels, but %i were "

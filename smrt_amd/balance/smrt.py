@@ -108,7 +108,12 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
     seeded_random_state = get_random_state(random_state)
     random_state = seeded_random_state.state
 
-    y_codes = np.searchsorted(present_classes, y)         # == LabelEncoder().fit(present_classes).transform(y)
+    if present_classes.dtype.kind in "iu" and 0 <= int(present_classes[0]) and int(present_classes[-1]) < (1 << 16):
+        lut = np.zeros(int(present_classes[-1]) + 1, dtype=np.intp)
+        lut[present_classes] = np.arange(len(present_classes))
+        y_codes = lut[y]                                  # same codes as below, one gather instead of a binary search per row
+    else:
+        y_codes = np.searchsorted(present_classes, y)     # == LabelEncoder().fit(present_classes).transform(y)
 
     if generate_args is None:
         generate_args = dict()

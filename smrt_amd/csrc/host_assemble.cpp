@@ -8,6 +8,8 @@
 #include "../../include/smrt_hip.h"
 
 #include <algorithm>
+#include <atomic>
+#include <cstdint>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -85,4 +87,42 @@ extern "C" int smrt_assemble_rows_part(const void* X, int32_t x_is_f32, int64_t 
                                        const float* synth, int64_t n_synth, int64_t ld_synth,
                                        const int64_t* order, int64_t n_out, double* out, int32_t n_threads, int32_t which) {
     return assemble<float>(X, x_is_f32, n_orig, d, ldx, synth, n_synth, ld_synth, order, n_out, out, n_threads, which);
+}
+
+namespace {
+// An IEEE value is NaN or infinite exactly when its exponent field is all ones: the largest |bit pattern| of a range says
+// whether any element is.  Integer max over the words vectorises (AVX2 clone picked at load time where the CPU has it).
+__attribute__((target_clones("avx2", "default")))
+bool finite_f32(const uint32_t* w, int64_t n) {
+    uint32_t m = 0;
+    for (int64_t i = 0; i < n; ++i) { const uint32_t a = w[i] & 0x7fffffffu; m = a > m ? a : m; }
+    return m < 0x7f800000u;
+}
+__attribute__((target_clones("avx2", "default")))
+bool finite_f64(const uint32_t* w, int64_t n) {          // little-endian: the high word of element i is w[2 i + 1]
+    uint32_t m = 0;
+    for (int64_t i = 0; i < n; ++i) { const uint32_t a = w[2 * i + 1] & 0x7fffffffu; m = a > m ? a : m; }
+    return m < 0x7ff00000u;
+}
+}  // namespace
+
+// check_array's finiteness sweep over X (smrt/balance/base.py:24 via sklearn), on every core instead of one: 1 when every
+// element is finite, 0 when one is NaN or infinite, -1 on a bad argument.  The caller lets sklearn produce the error.
+extern "C" int smrt_all_finite(const void* X, int32_t x_is_f32, int64_t n, int32_t n_threads) {
+    if (!X || n < 0) return -1;
+    std::atomic<int> ok{1};
+    auto run = [&](int64_t lo, int64_t hi) {
+        if (!(x_is_f32 ? finite_f32((const uint32_t*)X + lo, hi - lo) : finite_f64((const uint32_t*)X + 2 * lo, hi - lo))) ok.store(0);
+    };
+    const int64_t min_elems = 1 << 18;
+    const int nt = std::max(1, (int)std::min<int64_t>(n_threads, (n + min_elems - 1) / min_elems));
+    if (nt == 1) { run(0, n); return ok.load(); }
+    std::vector<std::thread> pool;
+    const int64_t per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t lo = t * per, hi = std::min<int64_t>(n, lo + per);
+        if (lo < hi) pool.emplace_back(run, lo, hi);
+    }
+    for (auto& th : pool) th.join();
+    return ok.load();
 }

@@ -147,3 +147,31 @@ def test_assemble_rows_matches_numpy():
         assert np.array_equal(sa.synthetic(S[:, :3]), ref)
     with pytest.raises(ValueError):
         _hip.SplitAssembly(big, 37, None).synthetic(S[:5, :3])
+
+
+def test_all_finite_sweep_and_validation_error_text():
+    """smrt_all_finite (the multi-threaded stand-in for check_array's finiteness pass): NaN / +-inf anywhere, fp32 and
+    fp64, largest finite values, and validation still raising sklearn's own message."""
+    from sklearn.utils.validation import check_array
+    from smrt_amd import _hip
+    from smrt_amd.balance.base import validate_X_y_ratio_classes
+    rs = np.random.RandomState(0)
+    for dtype, big in ((np.float32, 3.4e38), (np.float64, 1.7e308)):
+        X = rs.uniform(-1, 1, size=(70001, 16)).astype(dtype)
+        X[0, 0], X[-1, -1] = big, -big
+        for nt in (1, 5):
+            assert _hip.all_finite(X, nt)
+        for bad in (np.nan, np.inf, -np.inf):
+            for pos in ((0, 0), (35000, 7), (70000, 15)):
+                Y = X.copy()
+                Y[pos] = bad
+                assert not _hip.all_finite(Y, 4)
+    X = rs.uniform(size=(70000, 16)).astype(np.float32)               # >= 2^20 elements: the fast path of validation
+    y = (np.arange(70000) % 7 == 0).astype(int)
+    assert validate_X_y_ratio_classes(X, y, 0.5, copy=False, keep_float32=True)[0] is X
+    X[123, 4] = np.nan
+    with pytest.raises(ValueError) as ours:
+        validate_X_y_ratio_classes(X, y, 0.5)
+    with pytest.raises(ValueError) as theirs:
+        check_array(X)
+    assert str(ours.value) == str(theirs.value)
