@@ -1,15 +1,16 @@
 // Two-kernel training step for nets that fit in LDS (tabular-sized VAEs, e.g. 64-128-(16,16)-128-64:
 // 96 KB of weights + 43 KB of activations per workgroup).
 //
-//   fused_fwd_bwd_kernel : one workgroup (4 waves) owns 16 consecutive rows of the mini-batch and carries
+//   fused_fwd_bwd_kernel : one workgroup (8 waves) owns 16 consecutive rows of the mini-batch and carries
 //       them through EVERY layer, forward, loss and backward-through-activations.  All weights are staged
 //       into LDS by ONE batch of wide loads; after that nothing on the critical path touches global
 //       memory: activations stay in LDS between layers, both MFMA operands are LDS reads, stage
 //       barriers wait for LDS only.  Layer outputs and pre-activation gradients are streamed to global
 //       memory fire-and-forget for the second kernel.
 //   fused_dw_opt_kernel  : one wave per 16x16 tile of [X | 1]^T . dPre (all layers in one grid); the
-//       epilogue adds L2, undoes dropout, clips and applies the optimizer in place.  The last workgroup
-//       to finish advances the step counter / Adam powers (ticket counter, no spinning).
+//       epilogue adds L2, undoes dropout, clips and applies the optimizer in place.  The step counter / Adam powers
+//       are advanced by workgroup 0 at once, or -- under Adam, which reads them here -- by the last workgroup to
+//       finish (ticket counter, no spinning).
 //
 // On this machine a dependent global-memory round trip inside these tiny launches costs ~2.5 us, more than
 // all the arithmetic of a layer, so both kernels are built around "one batch of loads, then compute".
