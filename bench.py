@@ -155,6 +155,53 @@ def balance_c3_wallclock(dist, dev):
             "parallelism": "per-class jobs over %d rank(s)" % (dist.get_world_size() if dist is not None else 1)}
 
 
+def dp_c4_throughput(dist, dev, rank, world, rows_per_gpu=262144, global_batch=65536, epochs=2):
+    """Config C4, scaled to `rows_per_gpu` rows per rank: ONE class trained data-parallel on the
+    reference's own network 784-450-(10,10)-450-784 (adam, global batch 65 536).  Every mini-batch of the reference's
+    schedule is cut into `world` row stripes; per step smrt_vae_grad_step_async -> all_reduce(SUM) of 720 805 floats
+    (RCCL over xGMI) -> smrt_vae_apply_grads_async.  World 1 runs the same two halves without the collective."""
+    import torch
+    from smrt_amd import _hip
+    from smrt_amd.autoencode.data_parallel import DataParallelTrainer, plan_stripes
+    from smrt_amd.autoencode.topography import VAETopography
+    d, hidden, z = 784, [450], 10
+    flop_per_sample = 6 * (d * 450 + 2 * 450 * z + z * 450 + 450 * d) - 2 * d * 450
+    n_rows = rows_per_gpu * world
+    plan = plan_stripes(n_rows, global_batch, world)
+    n_local = sum(int(b[rank + 1] - b[rank]) for _, _, b in plan)
+    g = torch.Generator(device=dev).manual_seed(42 + rank)
+    X = (torch.rand((n_local, d), generator=g, device=dev) * (torch.rand((n_local, d), generator=g, device=dev) > 0.8)).float()
+    sess = _hip.VaeHandle(n_features=d, hidden=hidden, n_latent=z, activation="sigmoid", optimizer="adam",
+                          learning_rate=0.001, l2_penalty=1e-4, clip=True, gclip_min=-5.0, gclip_max=5.0, eps=1e-10,
+                          dropout=1.0, seed=42, max_batch=(global_batch + world - 1) // world + 1, device=dev.index)
+    try:
+        topo = VAETopography(n_hidden=hidden, input_shape=d, activation="sigmoid", n_latent_factors=z, random_state=42)
+        sess.set_params(VAETopography.join_flat(topo.initial_parameters()))
+        tr = DataParallelTrainer(sess, (X, d), n_rows, global_batch, rank, world, dist)
+        tr.run_epochs(1)                                        # warm-up (RCCL channels, kernels)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        costs, _ = tr.run_epochs(epochs)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        sps = n_rows * epochs / dt
+        return {"workload": "C4 (scaled): one class %d x 784, VAE 784-450-(10,10)-450-784, adam, global batch %d, "
+                            "%d epochs, row stripes over %d rank(s)" % (n_rows, global_batch, epochs, world),
+                "samples_per_s": sps, "ms_per_step": 1e3 * dt / (epochs * len(plan)), "steps_per_epoch": len(plan),
+                "tflops_per_gpu": sps * flop_per_sample / 1e12 / world, "allreduce_floats": int(sess.dp_count),
+                "final_cost": float(costs[-1]), "scaling": "weak (rows per rank fixed, global batch fixed)"}
+    finally:
+        sess.close()
+
+
 def balance_wallclock(with_cpu):
     """End-to-end smrt_balance(X, y, 128, 16) on C2, host arrays in -> host arrays out (API defaults: 20 epochs, batch
     128, rms_prop, balance_ratio 0.2 -> 176 470 synthetic rows, shuffled fp64 output of 1 176 470 x 64).  Median of 3 after
@@ -197,6 +244,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-balance", action="store_true", help="skip the end-to-end smrt_balance wall-clock leg")
+    ap.add_argument("--legs-timeout", type=float, default=240.0,
+                    help="seconds the end-to-end legs after the timed region may take before the line is printed without them")
     ap.add_argument("--no-diag", action="store_true", help="skip the measured-peak / latency-floor kernels (rocprof runs)")
     args = ap.parse_args()
 
@@ -310,13 +359,35 @@ def main():
             out["smrt_balance"] = balance_wallclock(with_cpu=not args.no_cpu_baseline)
     sess.close()
     if not args.no_balance:
-        # every rank takes part (the class jobs are sharded over the ranks); a failure here must not cost the headline line
+        # The two multi-GPU legs: every rank takes part.  Neither a failure nor a hang in them may cost the headline line:
+        # exceptions are recorded in place of the result, and a watchdog prints the line as it stands and ends the process
+        # if the legs are not through after --legs-timeout seconds.
+        import threading
+
+        def bail():
+            if rank == 0:
+                out.setdefault("smrt_balance_c3", {"error": "timeout"})
+                out.setdefault("dp_c4", {"error": "timeout"})
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+
+        dog = threading.Timer(args.legs_timeout, bail)
+        dog.daemon = True
+        dog.start()
         try:
             c3 = balance_c3_wallclock(dist, dev)
         except Exception as e:      # noqa: BLE001
             c3 = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
             out["smrt_balance_c3"] = c3
+        try:
+            c4 = dp_c4_throughput(dist, dev, rank, world)
+        except Exception as e:      # noqa: BLE001
+            c4 = {"error": "%s: %s" % (type(e).__name__, e)}
+        if rank == 0:
+            out["dp_c4"] = c4
+        dog.cancel()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

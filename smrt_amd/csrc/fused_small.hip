@@ -31,6 +31,11 @@ namespace smrt {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+// The stage records carry their output block as two 32-bit halves; a pointer rebuilt from integers is a GENERIC pointer
+// to the compiler, and stores through it are flat_store: they count on lgkmcnt as well (every later LDS wait becomes
+// lgkmcnt(0)) and issue through both address paths.  These types keep the stores global_store.
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
 
 constexpr int FTM = 16;                 // rows per workgroup
 constexpr int FTHREADS = 512;          // 8 waves: two per SIMD, so one wave's epilogue/LDS latency hides under the other's MFMAs
@@ -62,6 +67,38 @@ __device__ __forceinline__ void lds_barrier() {
 #define STAMP() do { } while (0)
 #define STAMP_NS() do { } while (0)
 #endif
+
+// NB 16-wide k-blocks of one 16x16 output tile: every LDS fragment read first, then the MFMAs (4 independent chains).
+// ap: this lane's A fragment (activations [row c][k = 4 q ..], k contiguous: one ds_read_b128 per k-block).
+// bp: this lane's weight fragment; !TRANS: one ds_read_b128 per k-block, `bstep` floats apart;
+//     TRANS: the lane's four k values are 4 floats apart (k-quad interleaved image), k-blocks 64 floats apart.
+template <int NB, bool TRANS>
+__device__ __forceinline__ void k_chunk(const float* ap, const float* bp, int bstep,
+                                        f32x4& acc0, f32x4& acc1, f32x4& acc2, f32x4& acc3) {
+    f32x4 av[NB], bv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        // (the two layouts request their operands in opposite order: with a common first instruction hipcc hoists that
+        // read above the branch that selects the layout, and a read pending from another block makes it wait for ALL reads)
+        if constexpr (TRANS) {
+            const float* p = bp + 64 * j;
+            bv[j][0] = p[0]; bv[j][1] = p[4]; bv[j][2] = p[8]; bv[j][3] = p[12];
+            av[j] = *reinterpret_cast<const f32x4*>(ap + 16 * j);
+        } else {
+            av[j] = *reinterpret_cast<const f32x4*>(ap + 16 * j);
+            bv[j] = *reinterpret_cast<const f32x4*>(bp + j * bstep);
+        }
+        // Pin "reads in consumption order, all requested before the first MFMA".  Left alone, hipcc either sinks each
+        // LDS read to just before its MFMA or issues the reads in an order of its own, and then the first MFMA waits
+        // for (nearly) all of them; pinned, the waits count down lgkmcnt(2 NB - 2), (2 NB - 4), ...
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        MFMA16(av[j][0], bv[j][0], acc0); MFMA16(av[j][1], bv[j][1], acc1);
+        MFMA16(av[j][2], bv[j][2], acc2); MFMA16(av[j][3], bv[j][3], acc3);
+    }
+}
 
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 
@@ -119,6 +156,15 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
         for (int i = (a.img_total >> 2) + tid; i < a.lds_total / 4; i += FTHREADS) l4[i] = z4;
         lds_barrier();
     }
+    // injected epsilon into its LDS tile: the reparameterisation below must not contain a global load, or the compiler
+    // puts an s_waitcnt vmcnt(0) in front of it that also waits for every activation store still draining
+    if (a.eps_in) {
+        float* es0 = lds + a.lds_e;
+        for (int i = tid, u = 0; i < rows_here * Z; i += FTHREADS, ++u) {
+            const int r = i / Z, k = i - r * Z;
+            es0[r * a.s_z + k] = (u == 0) ? eps_pre[0] : (u == 1 ? eps_pre[1] : a.eps_in[(long)r0 * Z + i]);
+        }
+    }
     // X tile into LDS (zeros on padded rows)
     if (x_fast) {
         if (tid < FTM * xf4_per_row) {
@@ -158,8 +204,8 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
         const int nn = UNI(d1.x), N = UNI(d1.y), kind = UNI(d1.z), act = UNI(d1.w);
         const int out_off = UNI(d2.x), s_out = UNI(d2.y), b_off = UNI(d2.z), aux_off = UNI(d2.w);
         const int s_aux = UNI(d3.x), NF = UNI(d3.y), trans = UNI(d3.z);
-        float* gblk = reinterpret_cast<float*>(((unsigned long long)(unsigned)UNI(d4.y) << 32) | (unsigned)UNI(d4.x))
-                      + (long)blockIdx.x * NF * 16;
+        gfloat* gblk = (gfloat*)(((unsigned long long)(unsigned)UNI(d4.y) << 32) | (unsigned)UNI(d4.x))
+                       + (long)blockIdx.x * NF * 16;
         const int N16 = (N + 15) & ~15;
         const float* ap = lds + in_off + c * sin + 4 * q;
         // the next stage's record is fetched now (the table has room for a read past the last stage)
@@ -170,41 +216,36 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
         for (int n0 = wave * 16; n0 < N16; n0 += 16 * FWAVES) {
             const int n = n0 + c;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-            // 128-wide k chunks (8 k-blocks of 16): ALL of a chunk's fragments are requested first, straight-line, then
-            // its 32 MFMAs run into 4 independent chains while the later reads are still landing (the compiler counts
-            // lgkmcnt down block by block).  Nets on this path have K <= 128 almost always, i.e. one chunk per stage.
-            // k-blocks past K16 are skipped by wave-uniform branches; no clamped addresses, no per-block selects.
+            // k runs in chunks of NB 16-wide k-blocks, NB a compile-time 8 / 4 / 2 / 1: a chunk is straight-line code -- ALL its
+            // fragments are requested first, then its 4 NB MFMAs run into 4 independent chains while the later reads are
+            // still landing (the compiler counts lgkmcnt down block by block; with run-time guards around the blocks it
+            // waited for every read before the first MFMA and copied the fragment registers around the guards).  Nets on
+            // this path have K in {16, 32, 64, 128} almost always, i.e. exactly one chunk per stage.
             const int nb_all = K16 >> 4;
+            const float* apc = ap;
+            const float* bp = trans ? lds + w_off + ((((n >> 2) * nn) + 4 * q) << 2) + (n & 3)     // Wop[k][n] = W[kf = n][nf = k]
+                                    : lds + w_off + ((q * nn + n) << 2);                          // Wop[k][n] = W[kf = k][nf = n]
+            const int bstep = trans ? 64 : (nn << 4);                                             // floats per 16 k
+            int left = nb_all;
 #pragma unroll 1
-            for (int kc = 0; kc < nb_all; kc += 8) {
-                const int nb = min(8, nb_all - kc);
-                f32x4 av[8], bv[8];
-                const float* apc = ap + kc * 16;
-                if (!trans) {
-                    const float* bp = lds + w_off + (((q + kc * 4) * nn + n) << 2);      // Wop[k][n] = W[kf = k][nf = n]
-                    const int bstep = nn << 4;                                           // 16 k = 4 k-quads of nn float4
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j < nb) {
-                            av[j] = *reinterpret_cast<const f32x4*>(apc + 16 * j);
-                            bv[j] = *reinterpret_cast<const f32x4*>(bp + j * bstep);
-                        }
-                } else {
-                    const float* bp = lds + w_off + ((((n >> 2) * nn) + 4 * q + kc * 16) << 2) + (n & 3);   // Wop[k][n] = W[kf = n][nf = k]
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j < nb) {
-                            av[j] = *reinterpret_cast<const f32x4*>(apc + 16 * j);
-                            const float* p = bp + 64 * j;
-                            bv[j][0] = p[0]; bv[j][1] = p[4]; bv[j][2] = p[8]; bv[j][3] = p[12];
-                        }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (j < nb) {
-                        MFMA16(av[j][0], bv[j][0], acc0); MFMA16(av[j][1], bv[j][1], acc1);
-                        MFMA16(av[j][2], bv[j][2], acc2); MFMA16(av[j][3], bv[j][3], acc3);
-                    }
+            for (; left >= 8; left -= 8) {
+                if (trans) k_chunk<8, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+                else       k_chunk<8, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+                apc += 128; bp += 8 * bstep;
+            }
+            if (left & 4) {
+                if (trans) k_chunk<4, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+                else       k_chunk<4, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+                apc += 64; bp += 4 * bstep;
+            }
+            if (left & 2) {
+                if (trans) k_chunk<2, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+                else       k_chunk<2, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+                apc += 32; bp += 2 * bstep;
+            }
+            if (left & 1) {
+                if (trans) k_chunk<1, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+                else       k_chunk<1, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
             }
             float v[4];
 #pragma unroll
@@ -212,7 +253,7 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
             // rows 4q .. 4q+3 of column n.  Workspace rows are padded to a multiple of 16, so rows past the batch are
             // computed and stored like the others (their dPre is forced to 0, nothing reads them).
             float* o = lds + out_off + (4 * q) * s_out + n;
-            float* g = gblk + n * 16 + 4 * q;
+            gfloat* g = gblk + n * 16 + 4 * q;
             if (kind <= FK_FWD_HEADS) {
                 // y = act(x.W + b)                                                     layer.py:368
                 if (n < N) {
@@ -222,7 +263,7 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
                     act_fwd4(act, v);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r * s_out] = v[r];
-                    *reinterpret_cast<float4*>(g) = make_float4(v[0], v[1], v[2], v[3]);
+                    *(gf32x4*)g = f32x4{v[0], v[1], v[2], v[3]};
                 }
             } else if (kind == FK_FWD_BCE) {
                 // sigmoid output + clipped Bernoulli NLL + dL/dpre (layer.py:333-338, _ae_utils.py:31-32)
@@ -243,7 +284,7 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
                         v[r] = valid ? dp * p * (1.0f - p) : 0.0f;
                         o[r * s_out] = v[r];
                     }
-                    *reinterpret_cast<float4*>(g) = make_float4(v[0], v[1], v[2], v[3]);
+                    *(gf32x4*)g = f32x4{v[0], v[1], v[2], v[3]};
                 }
             } else if (kind == FK_BWD_ACT) {
                 // dPre_prev = (dPre . W^T) * act'(y_prev); pad columns come out as exact zeros (zero weights, zero y)
@@ -254,7 +295,7 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
                 act_bwd4(act, yv, v);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r * s_out] = v[r];
-                *reinterpret_cast<float4*>(g) = make_float4(v[0], v[1], v[2], v[3]);
+                *(gf32x4*)g = f32x4{v[0], v[1], v[2], v[3]};
             } else {
                 // FK_BWD_LATENT: v = dL/dz through the reparameterisation and the KL term into both heads
                 //   dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B     layer.py:279, _ae_utils.py:49
@@ -281,8 +322,8 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
                         o[r * s_out] = g_mu[r];
                         o[r * s_out + Z] = g_ls[r];
                     }
-                    *reinterpret_cast<float4*>(g) = make_float4(g_mu[0], g_mu[1], g_mu[2], g_mu[3]);
-                    *reinterpret_cast<float4*>(g + Z * 16) = make_float4(g_ls[0], g_ls[1], g_ls[2], g_ls[3]);
+                    *(gf32x4*)g = f32x4{g_mu[0], g_mu[1], g_mu[2], g_mu[3]};
+                    *(gf32x4*)(g + Z * 16) = f32x4{g_ls[0], g_ls[1], g_ls[2], g_ls[3]};
                 }
             }
         }
@@ -300,13 +341,13 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
             // z = mu + eps * exp(log_sigma)  (layer.py:279) and the KL row terms (_ae_utils.py:49)
             const float* o = lds + out_off;
             float* zg = a.Zb_g + (long)blockIdx.x * ((Z + 15) & ~15) * 16;    // blocked transposed [rup16(Z)][16]
-            for (int i = tid, u = 0; i < FTM * Z; i += FTHREADS, ++u) {
+            for (int i = tid; i < FTM * Z; i += FTHREADS) {
                 const int r = i / Z, k = i - r * Z;
                 float z = 0.0f;                                              // finite filler for the padded rows
                 if (r < rows_here) {
                     const float mu = o[r * s_out + k], ls = o[r * s_out + Z + k];
                     float e;
-                    if (a.eps_in) e = (u == 0) ? eps_pre[0] : (u == 1 ? eps_pre[1] : a.eps_in[(long)r0 * Z + i]);
+                    if (a.eps_in) e = es[r * s_z + k];
                     else e = philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + r0) * Z + i);
                     const float el = __expf(ls);
                     z = mu + e * el;
