@@ -591,13 +591,18 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
     p.opt = h->cfg.optimizer; p.clip = h->cfg.clip; p.has_drop = h->has_drop; p.has_l2 = h->has_l2;
     p.lr = h->cfg.learning_rate; p.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
     p.gmin = h->cfg.gclip_min; p.gmax = h->cfg.gclip_max; p.keep = h->cfg.dropout_keep;
+    // Step counter / beta powers: advanced by the optimizer's first block, except under Adam (every block reads the powers
+    // there).  The scalar cost is then only assembled when somebody reads it (the last batch of an epoch, base.py:222).
+    p.advance = h->cfg.optimizer != 2;
     { ProfScope ps(h, PK_OPT); launch_optimizer(s, p, nullptr); } ++launches;
     h->img_valid = false;
-    FinalizeArgs f{};
-    f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p; f.n_l2 = h->n_l2;
-    f.inv_batch = h->ae ? inv_batch / (float)h->D : inv_batch; f.l2 = p.l2; f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
-    f.st = h->st; f.advance = 1;
-    { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
+    if (o.cost_slot || !p.advance) {
+        FinalizeArgs f{};
+        f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p; f.n_l2 = h->n_l2;
+        f.inv_batch = h->ae ? inv_batch / (float)h->D : inv_batch; f.l2 = p.l2; f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
+        f.st = h->st; f.advance = p.advance ? 0 : 1;
+        { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
+    }
     h->last_epoch_launches = launches;
     return 0;
 }

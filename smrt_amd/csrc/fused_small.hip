@@ -414,6 +414,20 @@ __device__ __forceinline__ float opt_apply(int opt, float lr, float alpha, float
     }
 }
 
+// Four elements at once with ONE (uniform) switch around them.
+__device__ __forceinline__ void opt_apply4(int opt, float lr, float alpha, const float (&w)[4], const float (&g)[4],
+                                           float (&s0)[4], float (&s1)[4], float (&wn)[4]) {
+    switch (opt) {
+#define SMRT_OPT_CASE(K) _Pragma("unroll") for (int r = 0; r < 4; ++r) wn[r] = opt_apply(K, lr, alpha, w[r], g[r], s0[r], s1[r]); break
+        case 1: SMRT_OPT_CASE(1);
+        case 2: SMRT_OPT_CASE(2);
+        case 3: case 6: SMRT_OPT_CASE(3);
+        case 4: SMRT_OPT_CASE(4);
+        default: SMRT_OPT_CASE(0);
+#undef SMRT_OPT_CASE
+    }
+}
+
 __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs a) {
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -433,9 +447,14 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
     const DwTile T = a.tiles[live ? t : a.total_tiles - 1];
     const int m0 = T.m0, n0 = T.n0, fi = T.fi, fo = T.fo, rows = a.rows;
 
-    // ---- batch 1 of loads: the optimizer operands of this lane's four output elements
+    // ---- batch 1 of loads: the optimizer operands of this lane's four output elements.  Every load is UNCONDITIONAL and
+    // from a clamped, always-valid address (both slot buffers exist under every optimizer; without dropout the weight
+    // buffer stands in for the post-dropout weights and the mask): a load under a branch or a select-on-condition makes
+    // the compiler wait for it at the join -- four dependent memory round trips here before the GEMM loads were requested.
     const bool has_s0 = a.opt != 0 && a.opt != 5;
     const bool has_s1 = a.opt == 1 || a.opt == 2 || a.opt == 4;
+    const float* wdp = a.has_drop ? a.Wd : a.W;
+    const float* mkp = a.has_drop ? a.mask : a.W;
     const int col = n0 + c;
     long idx[4]; bool ok[4];
     float w[4], s0[4], s1[4], wd[4], mk[4];
@@ -445,10 +464,10 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
         ok[r] = live && row <= fi && col < fo;               // row == fi is the bias
         idx[r] = T.off + (long)min(row, fi) * T.ld + min(col, fo - 1);
         w[r] = a.W[idx[r]];
-        s0[r] = has_s0 ? a.s0[idx[r]] : 0.f;
-        s1[r] = has_s1 ? a.s1[idx[r]] : 0.f;
-        wd[r] = a.has_drop ? a.Wd[idx[r]] : w[r];
-        mk[r] = a.has_drop ? a.mask[idx[r]] : 1.f;
+        s0[r] = a.s0[idx[r]];
+        s1[r] = a.s1[idx[r]];
+        wd[r] = wdp[idx[r]];
+        mk[r] = mkp[idx[r]];
     }
     // Step-dependent scalars.  Only Adam reads them here (its bias-correction powers), so only Adam has to wait for
     // every workgroup before advancing them (ticket below: a device-scope atomic round trip at the tail of the launch).
@@ -482,6 +501,9 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
             av[j] = *reinterpret_cast<const f32x4*>(Ap + jb * NFA);
             bv[j] = *reinterpret_cast<const f32x4*>(Bp + jb * NFB);
         }
+        // all sixteen loads are requested before the first select below touches one of them (left alone, hipcc requests
+        // one operand's eight, waits for them, and only then requests the other's: two round trips instead of one)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool kin = (k0 + 16 * j) < rows16;
@@ -501,27 +523,39 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
     }
 
     BST(22);
-    // ---- epilogue: L2, dropout backward, value clip, optimizer (base.py:127-149)
+    // ---- epilogue: L2, dropout backward, value clip, optimizer (base.py:127-149).  Straight-line over the four elements
+    // (uniform flags select, one switch on the optimizer around all four); only the stores are predicated.
     float alpha = 0.f;
     if (a.opt == 2) alpha = a.lr * sqrtf(1.0f - b2pow) / (1.0f - b1pow);
     float l2acc = 0.f;
-    float wn[4];
+    float g[4], wn[4];
+    const bool l2on = a.has_l2 && T.l2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float g = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+        g[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
         const bool is_w = (m0 + 4 * q + r) < fi;
-        wn[r] = w[r];
+        const bool reg = ok[r] && is_w && l2on;
+        g[r] = reg ? g[r] + a.l2 * wd[r] : g[r];
+        l2acc += reg ? 0.5f * wd[r] * wd[r] : 0.f;
+        if (a.has_drop) g[r] = is_w ? (g[r] / a.keep) * mk[r] : g[r];
+    }
+    if (a.grad_out) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (ok[r]) a.grad_out[idx[r]] = g[r];
+    }
+    if (a.clip) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[r] = fminf(fmaxf(g[r], a.gmin), a.gmax);
+    }
+    opt_apply4(a.opt, a.lr, alpha, w, g, s0, s1, wn);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
         if (ok[r]) {
-            if (is_w) {
-                if (a.has_l2 && T.l2) { g += a.l2 * wd[r]; l2acc += 0.5f * wd[r] * wd[r]; }
-                if (a.has_drop) g = (g / a.keep) * mk[r];
-            }
-            if (a.grad_out) a.grad_out[idx[r]] = g;
-            if (a.clip) g = fminf(fmaxf(g, a.gmin), a.gmax);
-            wn[r] = opt_apply(a.opt, a.lr, alpha, w[r], g, s0[r], s1[r]);
             a.W[idx[r]] = wn[r];
             if (has_s0) a.s0[idx[r]] = s0[r];
             if (has_s1) a.s1[idx[r]] = s1[r];
+        } else {
+            wn[r] = w[r];
         }
     }
     // the LDS-image twin read by the next step's forward/backward kernel: this lane's four fan-in rows of one

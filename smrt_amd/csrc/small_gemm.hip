@@ -132,8 +132,25 @@ __global__ __launch_bounds__(256, 2) void small_gemm_kernel(const GemmArgs a) {
     __shared__ float red[4 * ST * SRED];
     __shared__ float sred[4];
     const int m0 = blockIdx.y * ST, n0 = blockIdx.x * ST;
-    const f32x4v v = small_tile<ALAY, BLAY, false>(a.A, a.lda, a.M, a.B, a.ldb, a.N, m0, n0, a.K, red);
     const int row = m0 + (threadIdx.x >> 3), col0 = n0 + (threadIdx.x & 7) * 4;
+    // ---- epilogue operands (bias, targets, producing layer's output, heads + epsilon): requested NOW, unconditionally and
+    // from clamped in-bounds addresses, so that they arrive under the main loop.  Loaded where they are used -- each under
+    // its own bounds check -- the compiler waits for every one of them separately: four to twelve dependent memory round
+    // trips behind the GEMM of a kernel that is latency-bound to begin with.
+    const int rowc = min(row, a.M - 1);
+    float pb[4] = {0.f, 0.f, 0.f, 0.f}, px[4] = {0.f, 0.f, 0.f, 0.f}, px2[4] = {0.f, 0.f, 0.f, 0.f}, pe[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int colc = min(col0 + c, a.N - 1);
+        if constexpr (EPI == EPI_BIAS_ACT || EPI == EPI_HEADS_SPLIT || EPI == EPI_BCE || EPI == EPI_MSE) pb[c] = a.bias[colc];
+        if constexpr (EPI == EPI_BCE || EPI == EPI_MSE || EPI == EPI_ACTGRAD || EPI == EPI_LATENT)
+            px[c] = a.aux[(long)rowc * a.ldaux + colc];
+        if constexpr (EPI == EPI_LATENT) {
+            px2[c] = a.aux[(long)rowc * a.ldaux + a.Z + colc];
+            pe[c] = a.aux2[(long)rowc * a.ldaux2 + colc];
+        }
+    }
+    const f32x4v v = small_tile<ALAY, BLAY, false>(a.A, a.lda, a.M, a.B, a.ldb, a.N, m0, n0, a.K, red);
     const bool rin = row < a.M;
     float lsum = 0.f;
     float o[4], o2[4];
@@ -143,13 +160,13 @@ __global__ __launch_bounds__(256, 2) void small_gemm_kernel(const GemmArgs a) {
 
     if constexpr (EPI == EPI_BIAS_ACT || EPI == EPI_HEADS_SPLIT) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (cin[c]) o[c] = act_fwd(a.act, v[c] + a.bias[col0 + c]);      // layer.py:368
+        for (int c = 0; c < 4; ++c) if (cin[c]) o[c] = act_fwd(a.act, v[c] + pb[c]);      // layer.py:368
     } else if constexpr (EPI == EPI_BCE) {
         // sigmoid output + clipped Bernoulli NLL + dL/dpre (layer.py:333-338, _ae_utils.py:31-32)
 #pragma unroll
         for (int c = 0; c < 4; ++c) if (cin[c]) {
-            const float p = fast_sigmoid(v[c] + a.bias[col0 + c]);
-            const float x = a.aux[(long)row * a.ldaux + col0 + c];
+            const float p = fast_sigmoid(v[c] + pb[c]);
+            const float x = px[c];
             const float pl = fmaxf(p, a.lo), pc = fminf(pl, a.hi), om = 1.0f - pc;
             lsum -= x * __logf(pc) + (1.0f - x) * __logf(om);
             const bool pass = (p >= a.lo) && (pl <= a.hi);
@@ -160,22 +177,21 @@ __global__ __launch_bounds__(256, 2) void small_gemm_kernel(const GemmArgs a) {
     } else if constexpr (EPI == EPI_MSE) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) if (cin[c]) {
-            const float y = act_fwd(a.act, v[c] + a.bias[col0 + c]);
-            const float d = y - a.aux[(long)row * a.ldaux + col0 + c];
+            const float y = act_fwd(a.act, v[c] + pb[c]);
+            const float d = y - px[c];
             lsum += d * d;
             o[c] = act_bwd(a.act, y, 2.0f * d * a.inv_batch);
         }
     } else if constexpr (EPI == EPI_ACTGRAD) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) if (cin[c]) o[c] = act_bwd(a.act, a.aux[(long)row * a.ldaux + col0 + c], v[c]);
+        for (int c = 0; c < 4; ++c) if (cin[c]) o[c] = act_bwd(a.act, px[c], v[c]);
     } else if constexpr (EPI == EPI_LATENT) {
         // v = dL/dz -> both heads: dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B   (layer.py:279, _ae_utils.py:49)
 #pragma unroll
         for (int c = 0; c < 4; ++c) if (cin[c]) {
-            const int col = col0 + c;
-            const float mu = a.aux[(long)row * a.ldaux + col];
-            const float ls = a.aux[(long)row * a.ldaux + a.Z + col];
-            const float e = a.aux2[(long)row * a.ldaux2 + col];
+            const float mu = px[c];
+            const float ls = px2[c];
+            const float e = pe[c];
             const float el = expf(ls);
             o[c] = act_bwd(a.act, mu, v[c] + mu * a.inv_batch);
             o2[c] = act_bwd(a.act, ls, v[c] * e * el + (expf(2.0f * ls) - 1.0f) * a.inv_batch);

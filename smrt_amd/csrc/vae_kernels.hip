@@ -414,29 +414,48 @@ __global__ __launch_bounds__(256) void optimizer_kernel(const OptArgs a) {
     __shared__ float red[4];
     const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     float l2acc = 0.f;
+    if (a.advance && blockIdx.x == 0 && threadIdx.x == 0) {
+        // every earlier kernel of the step has read the step scalars (stream order) and no block of this one does
+        a.st->step += 1;
+        a.st->b1pow *= 0.9f;
+        a.st->b2pow *= 0.999f;
+    }
     if (i0 < a.P) {
-        const OptSeg& sg = a.seg[find_seg(a.seg, a.n_seg, i0)];
-        const bool is_w = (i0 - sg.start) < sg.w_count;
+        // every operand is requested up front, unconditionally (both slot buffers exist under every optimizer; without
+        // dropout the weight buffer stands in for the post-dropout weights and the mask): a load under a branch is waited
+        // for at the join, one memory round trip per operand
+        const float* wdp = a.has_drop ? a.Wd : a.W;
+        const float* mkp = a.has_drop ? a.mask : a.W;
         float4 g = *reinterpret_cast<const float4*>(a.G + i0);
+        const float4 w = *reinterpret_cast<const float4*>(a.W + i0);
+        const float4 wd4 = *reinterpret_cast<const float4*>(wdp + i0);
+        const float4 mk4 = *reinterpret_cast<const float4*>(mkp + i0);
+        const float4 s0 = *reinterpret_cast<const float4*>(a.s0 + i0);
+        const float4 s1 = *reinterpret_cast<const float4*>(a.s1 + i0);
+        // the segment (layer) this quad belongs to: the records are kernel arguments, read with scalar loads for a uniform j
+        // and selected per lane (indexing the argument struct with a per-lane index turns into dependent vector loads)
+        long seg_start = a.seg[0].start, seg_wcount = a.seg[0].w_count;
+        int seg_l2 = a.seg[0].l2;
+#pragma unroll
+        for (int j = 1; j < MAX_LAYERS; ++j) {
+            const bool in = j < a.n_seg && i0 >= a.seg[j].start;
+            seg_start = in ? a.seg[j].start : seg_start;
+            seg_wcount = in ? a.seg[j].w_count : seg_wcount;
+            seg_l2 = in ? a.seg[j].l2 : seg_l2;
+        }
+        const bool is_w = (i0 - seg_start) < seg_wcount;
         for (int s = 1; s < a.splits; ++s) {
             const float4 t = *reinterpret_cast<const float4*>(a.G + (long)s * a.slab_stride + i0);
             g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
         }
-        float4 w = *reinterpret_cast<const float4*>(a.W + i0);
         float gv[4] = {g.x, g.y, g.z, g.w};
         float wv[4] = {w.x, w.y, w.z, w.w};
         if (is_w) {
-            float wd[4] = {wv[0], wv[1], wv[2], wv[3]};
-            float mk[4] = {1.f, 1.f, 1.f, 1.f};
-            if (a.has_drop) {
-                const float4 t = *reinterpret_cast<const float4*>(a.Wd + i0);
-                const float4 m = *reinterpret_cast<const float4*>(a.mask + i0);
-                wd[0] = t.x; wd[1] = t.y; wd[2] = t.z; wd[3] = t.w;
-                mk[0] = m.x; mk[1] = m.y; mk[2] = m.z; mk[3] = m.w;
-            }
+            const float wd[4] = {wd4.x, wd4.y, wd4.z, wd4.w};
+            const float mk[4] = {mk4.x, mk4.y, mk4.z, mk4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (a.has_l2 && sg.l2) {
+                if (a.has_l2 && seg_l2) {
                     gv[j] += a.l2 * wd[j];                      // tf.nn.l2_loss on the post-dropout tensor
                     l2acc += 0.5f * wd[j] * wd[j];
                 }
@@ -446,11 +465,8 @@ __global__ __launch_bounds__(256) void optimizer_kernel(const OptArgs a) {
         if (a.grad_out) *reinterpret_cast<float4*>(a.grad_out + i0) = make_float4(gv[0], gv[1], gv[2], gv[3]);
         float alpha = 0.f;
         if (a.opt == 2) alpha = a.lr * sqrtf(1.0f - a.st->b2pow) / (1.0f - a.st->b1pow);
-        float4 s0 = make_float4(0, 0, 0, 0), s1 = make_float4(0, 0, 0, 0);
         const bool has_s0 = a.opt != 0 && a.opt != 5;
         const bool has_s1 = a.opt == 1 || a.opt == 2 || a.opt == 4;
-        if (has_s0) s0 = *reinterpret_cast<const float4*>(a.s0 + i0);
-        if (has_s1) s1 = *reinterpret_cast<const float4*>(a.s1 + i0);
         float s0v[4] = {s0.x, s0.y, s0.z, s0.w}, s1v[4] = {s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

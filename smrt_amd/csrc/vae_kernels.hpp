@@ -111,9 +111,10 @@ struct OptArgs {
     float* s0; float* s1;
     float* grad_out;                 // optional: pre-clip gradient wrt the variables (internal layout)
     float* l2_partials;
-    const DevState* st;
+    DevState* st;
     int opt, clip, has_drop, has_l2;
     float lr, l2, gmin, gmax, keep;
+    int advance;                     // block 0 bumps step / beta powers (never under Adam, whose blocks all read them here)
 };
 
 struct DropArgs {
