@@ -233,6 +233,29 @@ def test_two_hidden_layers_odd_widths():
     h.close()
 
 
+@pytest.mark.parametrize("D,hidden,Z,act,opt", [
+    (100, [72], 5, "sigmoid", "rms_prop"),      # k extents 112 (4 + 2 + 1 blocks of 16), 80 (4 + 1), 16 (1)
+    (24, [176], 8, "tanh", "adam"),             # k extents 32 (2), 176 (8 + 2 + 1), 16 (1)
+])
+def test_fused_small_net_every_k_chunk(D, hidden, Z, act, opt, kernel_path):
+    """The LDS-resident two-kernel step walks k in compile-time chunks of 8 / 4 / 2 / 1 blocks of 16: nets whose padded
+    widths need every combination, at a full, a ragged and a one-row batch, with injected epsilon, vs the oracle step."""
+    rs = np.random.RandomState(19)
+    o = _oracle(D, hidden, Z, act=act, opt=opt, lr=0.01, rs=rs)
+    h = _handle(D, hidden, Z, act=act, opt=opt, lr=0.01, max_batch=48)
+    h.set_params(flatten_params(o.params))
+    for B in (48, 37, 1):
+        X, eps = rs.uniform(0, 1, size=(B, D)), rs.normal(size=(B, Z))
+        c_o, (gW, gb) = o.train_step(X, eps, return_grads=True)
+        c_h, g_h = h.train_step(X, eps, want_grads=True)
+        assert np.isclose(c_h, c_o, rtol=RTOL)
+        _close(g_h, _flat_grads(gW, gb), "grads B=%d" % B)
+        if kernel_path == "fused":
+            assert h.last_epoch_launches <= 4, "expected the two-kernel fused step (+ image build, + finalize)"
+    _close(h.get_params(), flatten_params(o.params), "params")
+    h.close()
+
+
 def test_bce_saturation_matches_ieee():
     """eps=1e-10: float32(1-eps) == 1.0f, so p == 1.0f is not clipped (inf / NaN cost exactly as IEEE says)."""
     D, hidden, Z = 4, [3], 2
