@@ -10,6 +10,10 @@ i.e. one pass of the hot path over the batch of synthetic input; value = rows tr
 With --gpus N every rank trains its own minority-class job (the per-class jobs of smrt_balance
 are independent: weak scaling, no collective on the data path).
 
+After the timed region (outside `value`) two end-to-end legs run at every N under a watchdog (--legs-timeout):
+`smrt_balance_c3` (config C3: 8 per-class fit -> generate jobs sharded over the ranks, no data-path collective) and
+`dp_c4` (config C4, scaled: ONE class trained data-parallel, all_reduce of the gradients per mini-batch over RCCL).
+
     python bench.py --gpus 1 --steps 20 --warmup 2
 """
 import argparse
@@ -237,6 +241,16 @@ def balance_wallclock(with_cpu):
     return out
 
 
+def note(rank, what):
+    """Progress line on stderr (rank 0): a long multi-GPU run is not silent, and a hang names the leg it is in."""
+    if rank == 0:
+        sys.stderr.write("[bench %6.1f s] %s\n" % (time.perf_counter() - T_START, what))
+        sys.stderr.flush()
+
+
+T_START = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -284,6 +298,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    note(rank, "handles ready, world %d" % world)
     if args.warmup > 0:
         sess.train_epochs(X_dev, BATCH, max(args.warmup, 2))  # >= 2 so the epoch graph is built here
     barrier()
@@ -296,6 +311,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert len(costs) == args.steps and np.all(np.isfinite(costs)), costs
+    note(rank, "timed region done: %.3f ms per step" % (1e3 * elapsed / args.steps))
 
     # ---- per-kernel timing of the same steps, hipEvents on the library's stream (eager launches)
     steps_per_epoch = (N_MINORITY + BATCH - 1) // BATCH
@@ -375,19 +391,25 @@ def main():
         dog = threading.Timer(args.legs_timeout, bail)
         dog.daemon = True
         dog.start()
+        import faulthandler
+        faulthandler.dump_traceback_later(max(args.legs_timeout - 5.0, 1.0), exit=False)      # where a hung leg hangs
+        note(rank, "leg smrt_balance_c3")
         try:
             c3 = balance_c3_wallclock(dist, dev)
         except Exception as e:      # noqa: BLE001
             c3 = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
             out["smrt_balance_c3"] = c3
+        note(rank, "leg dp_c4")
         try:
             c4 = dp_c4_throughput(dist, dev, rank, world)
         except Exception as e:      # noqa: BLE001
             c4 = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
             out["dp_c4"] = c4
+        note(rank, "legs done")
         dog.cancel()
+        faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -75,6 +75,11 @@ class DataParallelTrainer(object):
             raise ValueError("rank %d holds %d rows, its stripes need %d" % (rank, X_local[0].shape[0], n_local))
         self.grads = torch.zeros(sess.dp_count, dtype=torch.float32, device=sess.device)
         self.on_gpu = sess.device.type == "cuda"
+        # A host-side backend (gloo) reduces through host memory: it is handed a gradient buffer whose kernels have
+        # finished.  (Measured on MI355X / ROCm 7.2: a gloo all_reduce of a CUDA tensor entered while kernels are still
+        # queued on the current stream never returns; entered after a stream synchronise it takes 10 ms.)  RCCL is ordered
+        # on the stream itself and gets no synchronisation.
+        self.host_collective = bool(self.on_gpu and dist is not None and self.world > 1 and dist.get_backend() != "nccl")
 
     def run_epochs(self, n_epochs, early_stopping=False, min_change=1e-3):
         """Returns ``(costs, seconds)`` per finished epoch (cost of the last batch, base.py:222)."""
@@ -95,6 +100,8 @@ class DataParallelTrainer(object):
                     sess.dp_grad_step(self.X_local, off, rows, b, int(bounds[rank] - start), self.grads)
                     off += rows
                     if dist is not None and self.world > 1:
+                        if self.host_collective:
+                            stream.synchronize()
                         dist.all_reduce(self.grads)                    # SUM; RCCL ring / tree over xGMI under nccl
                     sess.dp_apply(self.grads, cost[ep:ep + 1] if i == len(self.plan) - 1 else None)
                 if early_stopping and dist is not None and self.world > 1:

@@ -33,11 +33,17 @@ def main():
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SMRT_BENCH_BACKEND", "nccl")      # gloo: rehearse several ranks on ONE GPU
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     from smrt_amd import _hip
     from smrt_amd.autoencode.data_parallel import DataParallelTrainer, plan_stripes
     from smrt_amd.autoencode.topography import VAETopography
