@@ -67,9 +67,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
         }
     } else if constexpr (EPI == EPI_HEADS_SPLIT) {
         // fused (z_mean | z_log_sigma) heads written to two contiguous [n][Z] outputs   autoencoder.py:500
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        float bj[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int col = n0 + (wave & 1) * 32 * WN + j * 32 + (lane & 31);
+            bj[j] = a.bias[min(col, a.N - 1)];
+        }
         for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
             if (row < a.M && col < a.N) {
-                const float y = act_fwd(a.act, v + a.bias[col]);
+                const float y = act_fwd(a.act, v + bj[((col - n0) >> 5) % WN]);
                 if (col < a.Z) a.C[(long)row * a.Z + col] = y;
                 else           a.out2[(long)row * a.Z + (col - a.Z)] = y;
             }
@@ -112,14 +119,33 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
                     }
                 }
         } else {
-            for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-                if (row < a.M && col < a.N) {
-                    float d;
-                    const float p = bce_elem(v, a.aux[(long)row * a.ldaux + col], a.bias[col], d);
-                    a.C[(long)row * a.ldc + col] = d;
-                    if (a.out2) a.out2[(long)row * a.ldout2 + col] = p;
+            // Edge tiles (and the variant that also stores p): the same batches from CLAMPED addresses, only the stores and
+            // the loss sum are predicated.  A load inside the bounds check is waited for on the spot, and a lane with
+            // valid columns then walks through its 32-64 elements one memory round trip at a time.
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int col = n0 + wc * 32 * WN + j * 32 + r, colc = min(col, a.N - 1);
+                    const int rowb = m0 + wr * 32 * WM + i * 32 + 4 * h;
+                    const float b = a.bias[colc];
+                    float x[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        x[e] = a.aux[(long)min(rowb + (e & 3) + 8 * (e >> 2), a.M - 1) * a.ldaux + colc];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = rowb + (e & 3) + 8 * (e >> 2);
+                        if (row < a.M && col < a.N) {
+                            float d;
+                            const float p = bce_elem(acc[i][j][e], x[e], b, d);
+                            a.C[(long)row * a.ldc + col] = d;
+                            if (a.out2) a.out2[(long)row * a.ldout2 + col] = p;
+                        }
+                    }
                 }
-            });
         }
         const float tot = block_sum_256(lsum, red);
         if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
@@ -127,14 +153,32 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
         // plain auto-encoder output layer: y = act(.), squared error summed into a block partial and
         // dL/dpre = 2 (y - x) / (B D) * act'(y) emitted directly (autoencoder.py:260); a.inv_batch = 1 / (B D)
         float lsum = 0.f;
-        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-            if (row < a.M && col < a.N) {
-                const float y = act_fwd(a.act, v + a.bias[col]);
-                const float d = y - a.aux[(long)row * a.ldaux + col];
-                lsum += d * d;
-                a.C[(long)row * a.ldc + col] = act_bwd(a.act, y, 2.0f * d * a.inv_batch);
-            }
-        });
+        {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int col = n0 + wc * 32 * WN + j * 32 + r, colc = min(col, a.N - 1);
+                    const int rowb = m0 + wr * 32 * WM + i * 32 + 4 * h;
+                    const float b = a.bias[colc];
+                    float x[16];                      // targets: one batch from clamped addresses (see BCE)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        x[e] = a.aux[(long)min(rowb + (e & 3) + 8 * (e >> 2), a.M - 1) * a.ldaux + colc];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = rowb + (e & 3) + 8 * (e >> 2);
+                        if (row < a.M && col < a.N) {
+                            const float y = act_fwd(a.act, acc[i][j][e] + b);
+                            const float d = y - x[e];
+                            lsum += d * d;
+                            a.C[(long)row * a.ldc + col] = act_bwd(a.act, y, 2.0f * d * a.inv_batch);
+                        }
+                    }
+                }
+        }
         const float tot = block_sum_256(lsum, red);
         if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
     } else if constexpr (EPI == EPI_ACTGRAD) {
@@ -160,25 +204,63 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
                         a.C[(long)(rowb + (e & 3) + 8 * (e >> 2)) * a.ldc + col] = act_bwd(a.act, y[e], acc[i][j][e]);
                 }
         } else {
-            for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-                if (row < a.M && col < a.N)
-                    a.C[(long)row * a.ldc + col] = act_bwd(a.act, a.aux[(long)row * a.ldaux + col], v);
-            });
+            // edge tiles: the same batches from clamped addresses, predicated stores (see BCE)
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int col = n0 + wc * 32 * WN + j * 32 + r, colc = min(col, a.N - 1);
+                    const int rowb = m0 + wr * 32 * WM + i * 32 + 4 * h;
+                    float y[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        y[e] = a.aux[(long)min(rowb + (e & 3) + 8 * (e >> 2), a.M - 1) * a.ldaux + colc];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = rowb + (e & 3) + 8 * (e >> 2);
+                        if (row < a.M && col < a.N) a.C[(long)row * a.ldc + col] = act_bwd(a.act, y[e], acc[i][j][e]);
+                    }
+                }
         }
     } else if constexpr (EPI == EPI_LATENT) {
         // v = dL/dz.  Through the reparameterisation and the KL term into both heads:
         //   dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B     layer.py:279, _ae_utils.py:49
-        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-            if (row < a.M && col < a.N) {
-                const float mu = a.aux[(long)row * a.ldaux + col];
-                const float ls = a.aux[(long)row * a.ldaux + a.Z + col];
-                const float e = a.aux2[(long)row * a.ldaux2 + col];
-                const float dmu = v + mu * a.inv_batch;
-                const float dls = v * e * expf(ls) + (expf(2.0f * ls) - 1.0f) * a.inv_batch;
-                a.C[(long)row * a.ldc + col] = act_bwd(a.act, mu, dmu);
-                a.C[(long)row * a.ldc + a.Z + col] = act_bwd(a.act, ls, dls);
-            }
-        });
+        // N = Z is a fraction of a tile: every tile is an edge tile.  mu, log sigma and epsilon of a 32x32 sub-tile come in
+        // one batch from clamped addresses (see BCE); sub-tiles that lie wholly past N are skipped (wave-uniform).
+        {
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int colb = n0 + wc * 32 * WN + j * 32;
+                    if (colb >= a.N) continue;
+                    const int col = colb + r, colc = min(col, a.N - 1);
+                    const int rowb = m0 + wr * 32 * WM + i * 32 + 4 * h;
+                    float mu[16], ls[16], ee[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const long rowc = min(rowb + (e & 3) + 8 * (e >> 2), a.M - 1);
+                        mu[e] = a.aux[rowc * a.ldaux + colc];
+                        ls[e] = a.aux[rowc * a.ldaux + a.Z + colc];
+                        ee[e] = a.aux2[rowc * a.ldaux2 + colc];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = rowb + (e & 3) + 8 * (e >> 2);
+                        if (row < a.M && col < a.N) {
+                            const float v = acc[i][j][e];
+                            const float dmu = v + mu[e] * a.inv_batch;
+                            const float dls = v * ee[e] * expf(ls[e]) + (expf(2.0f * ls[e]) - 1.0f) * a.inv_batch;
+                            a.C[(long)row * a.ldc + col] = act_bwd(a.act, mu[e], dmu);
+                            a.C[(long)row * a.ldc + a.Z + col] = act_bwd(a.act, ls[e], dls);
+                        }
+                    }
+                }
+        }
     }
 #ifdef SMRT_STAMPS
     __syncthreads();
