@@ -61,17 +61,28 @@ def plan_class_jobs(costs, world):
     return owners
 
 
-def _exchange_block(dist, block, shape, src):
-    """Broadcast one finished fp32 block from its owner to every rank."""
+def _exchange_block(dist, slab_rows, src, mine, rows_dev=None):
+    """Broadcast one finished fp32 block from its owner to every rank, in place in ``slab_rows`` (this rank's view of
+    the block inside the synthetic slab; the owner's view already holds the rows).
+
+    RCCL (``nccl``) moves device memory: the owner sends the decoded rows straight from HBM when they are still there
+    (``rows_dev``), every other rank receives into a device buffer and downloads it into its slab -- no staging copy
+    on either side.  A host backend (``gloo``) broadcasts the slab view itself."""
     import torch
-    on_gpu = dist.get_backend() == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    if block is not None:
-        t = torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32)).to(dev)
+    view = torch.from_numpy(slab_rows)
+    if dist.get_backend() != "nccl":
+        dist.broadcast(view, src=src)
+        return
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if mine:
+        t = rows_dev if rows_dev is not None else view.to(dev)
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            t = t.contiguous().float()
     else:
-        t = torch.empty(shape, dtype=torch.float32, device=dev)
+        t = torch.empty(tuple(slab_rows.shape), dtype=torch.float32, device=dev)
     dist.broadcast(t, src=src)
-    return t.cpu().numpy()
+    if not mine:
+        view.copy_(t)
 
 
 def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, balance_ratio=0.2,
@@ -173,6 +184,7 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
     lap("split")
 
     blocks, cursor, drawn = [], 0, []
+    dev_rows = dict()                        # job -> decoded rows still in HBM (sent from there under RCCL)
     try:
         if n_fresh:
             from concurrent.futures import ThreadPoolExecutor
@@ -235,6 +247,8 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
                 # == generate(n=need, **generate_args); the decoded rows are downloaded straight into their slab
                 rows_dev = encoder.sess.decode(noise, to_host=False)
                 torch.from_numpy(synth[start:start + need]).copy_(rows_dev)
+                if world > 1 and tuple(rows_dev.shape) == (need, n_features):
+                    dev_rows[j] = rows_dev
             else:
                 z_mu, log_sigma = encoder.encode(subs[j][sample_idcs, :])         # == generate_from_sample(...)
                 z_mu += noise * np.exp(log_sigma)
@@ -246,10 +260,8 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
 
     lap("fit+gen")
     if world > 1:
-        for start, need, owner, mine in blocks:
-            got = _exchange_block(dist, synth[start:start + need] if mine else None, (need, n_features), owner)
-            if not mine:
-                synth[start:start + need] = got
+        for j, (start, need, owner, mine) in enumerate(blocks):
+            _exchange_block(dist, synth[start:start + need], owner, mine, dev_rows.pop(j, None))
 
     y_out = present_classes[y_out_codes]                  # back to the caller's label space (smrt.py:241)
 
