@@ -366,7 +366,7 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
     // both partial sums in one pass: wave shuffles, one LDS exchange, fixed summation order
     bce = wave_sum(bce); kl = wave_sum(kl);
     if (lane == 0) { red[wave] = bce; red2[wave] = kl; }
-    __syncthreads();
+    lds_barrier();                              // LDS only: the last stage's activation stores keep draining
     if (tid == 0) {
         float bsum = 0.f, ksum = 0.f;
 #pragma unroll
