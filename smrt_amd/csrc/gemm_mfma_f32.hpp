@@ -151,11 +151,13 @@ __device__ __forceinline__ void read_frag(const float* lds, int base_mn, int kb,
 // Accumulates A[m0.., kbeg..kend) * B[kbeg..kend), n0..) into acc[WM][WN].
 // bsum (optional): per-thread running sums over k of the B values this thread stages (Stage::add_to) -- the
 // weight-gradient kernel turns them into the bias gradient (column sums of dPre) without an extra row of MFMA tiles.
-template <int ALAY, int BLAY, int WM, int WN, bool A_ONES>
-__device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda, int M_data,
-                                          const float* __restrict__ B, long ldb, int N_data,
-                                          int m0, int n0, int kbeg, int kend,
-                                          float* ldsA, float* ldsB, f32x16 (&acc)[WM][WN], float4* bsum = nullptr) {
+// LI x LJ: how many of this wave's 32-row / 32-column blocks are multiplied (the rest lie wholly in the padding of an edge
+// tile; their accumulators stay zero).  Compile-time, so the main loop has no branch in it -- see gemm_tile below.
+template <int ALAY, int BLAY, int WM, int WN, bool A_ONES, int LI, int LJ>
+__device__ __forceinline__ void gemm_tile_impl(const float* __restrict__ A, long lda, int M_data,
+                                               const float* __restrict__ B, long ldb, int N_data,
+                                               int m0, int n0, int kbeg, int kend,
+                                               float* ldsA, float* ldsB, f32x16 (&acc)[WM][WN], float4* bsum) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -221,9 +223,9 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda,
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < LI; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j)
+                    for (int j = 0; j < LJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);
         }
         if (more) {
@@ -236,6 +238,28 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda,
             __syncthreads();
         }
     }
+}
+
+// Edge tiles of 784 / 450 / 20 / 10-wide layers are mostly padding (16 real columns in the last 128 of 784): a wave
+// multiplies only the blocks of its region that hold a real element.  The choice is made ONCE per tile, between complete
+// copies of the main loop (a branch around the MFMA group inside one loop makes hipcc spill the accumulators); it is
+// wave-uniform, and every copy passes the same barriers, so the waves of a workgroup may take different copies.
+template <int ALAY, int BLAY, int WM, int WN, bool A_ONES>
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda, int M_data,
+                                          const float* __restrict__ B, long ldb, int N_data,
+                                          int m0, int n0, int kbeg, int kend,
+                                          float* ldsA, float* ldsB, f32x16 (&acc)[WM][WN], float4* bsum = nullptr) {
+    const int wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    const int rem_m = M_data + (A_ONES ? 1 : 0) - (m0 + wr * 32 * WM), rem_n = N_data - (n0 + wc * 32 * WN);
+    const int li = __builtin_amdgcn_readfirstlane(rem_m <= 0 ? 0 : min(WM, (rem_m + 31) >> 5));
+    const int lj = __builtin_amdgcn_readfirstlane(rem_n <= 0 ? 0 : min(WN, (rem_n + 31) >> 5));
+#define SMRT_TILE(LI_, LJ_) gemm_tile_impl<ALAY, BLAY, WM, WN, A_ONES, LI_, LJ_>(A, lda, M_data, B, ldb, N_data, m0, n0, kbeg, kend, ldsA, ldsB, acc, bsum)
+    if (li == WM && lj == WN) { SMRT_TILE(WM, WN); return; }
+    if constexpr (WM == 2) { if (li == 2 && lj == 1) { SMRT_TILE(2, 1); return; } }
+    if constexpr (WN == 2) { if (li == 1 && lj == 2) { SMRT_TILE(1, 2); return; } }
+    if constexpr (WM == 2 || WN == 2) { if (li == 1 && lj == 1) { SMRT_TILE(1, 1); return; } }
+    SMRT_TILE(0, 0);            // nothing of this wave's region is real: it still stages its share of both operands
+#undef SMRT_TILE
 }
 
 // Visit every accumulator element of this thread: f(row, col, value) with global row/col.
