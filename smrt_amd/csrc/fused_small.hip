@@ -156,13 +156,19 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
         for (int i = (a.img_total >> 2) + tid; i < a.lds_total / 4; i += FTHREADS) l4[i] = z4;
         lds_barrier();
     }
-    // injected epsilon into its LDS tile: the reparameterisation below must not contain a global load, or the compiler
-    // puts an s_waitcnt vmcnt(0) in front of it that also waits for every activation store still draining
-    if (a.eps_in) {
+    // Epsilon into its LDS tile.  Injected values were fetched with the other loads (the reparameterisation below must not
+    // contain a global load, or the compiler puts an s_waitcnt vmcnt(0) in front of it that also waits for every
+    // activation store still draining).  The kernel's own epsilon (Philox, indexed by step and global row) depends on nothing that is still in flight: it is
+    // drawn HERE, while the weight image is on its way, instead of on the critical path between the heads and the decoder
+    // (ten Philox rounds + Box-Muller are ~300 dependent VALU instructions).
+    {
         float* es0 = lds + a.lds_e;
         for (int i = tid, u = 0; i < rows_here * Z; i += FTHREADS, ++u) {
             const int r = i / Z, k = i - r * Z;
-            es0[r * a.s_z + k] = (u == 0) ? eps_pre[0] : (u == 1 ? eps_pre[1] : a.eps_in[(long)r0 * Z + i]);
+            float e;
+            if (a.eps_in) e = (u == 0) ? eps_pre[0] : (u == 1 ? eps_pre[1] : a.eps_in[(long)r0 * Z + i]);
+            else e = philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + r0) * Z + i);
+            es0[r * a.s_z + k] = e;
         }
     }
     // X tile into LDS (zeros on padded rows)
@@ -346,13 +352,10 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
                 float z = 0.0f;                                              // finite filler for the padded rows
                 if (r < rows_here) {
                     const float mu = o[r * s_out + k], ls = o[r * s_out + Z + k];
-                    float e;
-                    if (a.eps_in) e = es[r * s_z + k];
-                    else e = philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + r0) * Z + i);
+                    const float e = es[r * s_z + k];                         // staged by the prologue
                     const float el = __expf(ls);
                     z = mu + e * el;
                     zs[r * s_z + k] = z;
-                    es[r * s_z + k] = e;
                     kl += -0.5f * (1.0f + 2.0f * ls - mu * mu - el * el);
                 }
                 zg[k * 16 + r] = z;
