@@ -412,9 +412,17 @@ def main():
         faulthandler.cancel_dump_traceback_later()
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
+        # the line is out: a rank that does not come back from the closing barrier (a peer died in a leg) must not keep
+        # the launcher waiting
+        import threading
+        last = threading.Timer(30.0, lambda: os._exit(0))
+        last.daemon = True
+        last.start()
         dist.barrier()
         dist.destroy_process_group()
+        last.cancel()
 
 
 if __name__ == "__main__":
