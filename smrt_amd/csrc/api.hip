@@ -293,8 +293,18 @@ static int choose_splits(const smrt_vae* h, int rows) {
     return best;
 }
 
+// Fused forward/backward kernel beyond 512 rows (nets that fit in LDS): up to this many rows one 16-row workgroup per
+// CU and round still beats the per-layer GEMM chain, whose launches are latency-bound at these widths.
+constexpr int FUSED_ROWS_MAX = 8192;
+// Row ranges of the slab weight-gradient kernel: at least 8 row blocks (one batch of loads) per range, at most 32 ranges.
+static int fused_slab_splits(int rows) {
+    const int nblk = (rows + 15) / 16;
+    return std::max(1, std::min(32, nblk / 8));
+}
+
 static int ensure_train(smrt_vae* h, int rows) {
-    const int splits = choose_splits(h, rows);
+    int splits = choose_splits(h, rows);
+    if (h->fused && rows > 512 && rows <= FUSED_ROWS_MAX) splits = std::max(splits, fused_slab_splits(rows));
     if (splits <= h->g_splits_cap && rows <= h->cap_rows) return 0;
     drop_graph(h);
     HIPC(hipStreamSynchronize(h->stream));
@@ -393,11 +403,14 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
 
     int n_bce = 0;
     int n_kl = h->ae ? 0 : reparam_blocks(rows, Z);
-    const bool fused_step = h->fused && mode == 0 && rows <= 512;      // two-kernel step on the transposed workspace
+    const bool fused_big = h->fused && mode == 0 && rows > 512 && rows <= FUSED_ROWS_MAX &&
+                           fused_slab_splits(rows) <= h->g_splits_cap;    // fused fwd/bwd + slab dW + optimizer sweep
+    const bool fused_small = h->fused && mode == 0 && rows <= 512;      // two-kernel step on the transposed workspace
+    const bool fused_step = fused_small || fused_big;
     if (fused_step) {
         if (h->has_drop) {           // the image follows the post-dropout weights of this step
             launch_build_image(s, h->Wd, h->stage_tab, h->Wimg, (int)(h->P_int / 4)); ++launches;
-        } else if (!h->img_valid) {
+        } else if (!h->img_valid || fused_big) {     // (the optimizer sweep of the large-batch path does not write the image)
             launch_build_image(s, h->W, h->stage_tab, h->Wimg, (int)(h->P_int / 4)); ++launches;
             h->img_valid = true;
         }
@@ -518,7 +531,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         ++launches;
     }
     // ---- small nets, small batches: dW + optimizer in one launch, cost only when somebody reads it
-    if (fused_step) {
+    if (fused_small) {
         DwOptArgs d{};
         const int tb = h->tiles16;
         d.tiles = h->tile_tab; d.total_tiles = tb; d.rows = rows;
@@ -555,9 +568,16 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
     }
     // ---- all weight/bias gradients in one launch
     const bool small = rows <= SMALL_M_MAX;              // register-fed 32x32 tiles, one slab, bias row via a ones index
-    const int splits = small ? 1 : std::min(choose_splits(h, rows), h->g_splits_cap);
+    const int splits = fused_big ? fused_slab_splits(rows)
+                                 : (small ? 1 : std::min(choose_splits(h, rows), h->g_splits_cap));
     const bool big = dw_big(h, rows);
-    {
+    if (fused_big) {
+        DwSlabArgs d{};
+        d.tiles = h->tile_tab; d.total_tiles = h->tiles16; d.rows = rows;
+        d.blocks_per_split = (((rows + 15) / 16) + splits - 1) / splits;
+        d.G = h->G; d.slab_stride = h->P_int;
+        { ProfScope ps(h, PK_DW); launch_fused_dw_slab(s, d, splits); } ++launches;
+    } else {
         DwArgs d{};
         const int t = small ? 32 : (big ? 128 : 64);
         int tb = 0;

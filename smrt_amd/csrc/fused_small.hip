@@ -595,6 +595,69 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
     BST(24);
 }
 
+// =====================================================================================
+// The same weight + bias gradient tiles for LARGER mini-batches of a net that fits the fused forward/backward kernel:
+// the rows are cut into `splits` ranges of whole 16-row blocks (blockIdx.y), a wave sums its 16x16 tile of
+// [X | 1]^T . dPre over one range and writes it into slab blockIdx.y of the gradient buffer, in the flat parameter
+// layout optimizer_kernel reduces (deterministic: one writer per element and slab, fixed summation order).
+// =====================================================================================
+__global__ __launch_bounds__(BTHREADS) void fused_dw_slab_kernel(const DwSlabArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    const int t = blockIdx.x * 4 + wave;
+    const bool live = t < a.total_tiles;
+    const DwTile T = a.tiles[live ? t : a.total_tiles - 1];
+    const int m0 = T.m0, n0 = T.n0, fi = T.fi, fo = T.fo;
+    const int m = m0 + c, mm = min(m, fi - 1);
+    const int n = n0 + c, nn = min(n, fo - 1);
+    const int NFA = (fi + 15) & ~15, NFB = (fo + 15) & ~15;
+    const float* Ap = T.A + mm * 16 + 4 * q;
+    const float* Bp = T.B + nn * 16 + 4 * q;
+    const bool ones = (m == fi);
+    const int nblk = (a.rows + 15) >> 4;                         // 16-row blocks in all
+    const int b0 = blockIdx.y * a.blocks_per_split, b1 = min(nblk, b0 + a.blocks_per_split);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    for (int kb = b0; kb < b1; kb += 8) {                        // 8 row blocks (16 loads per lane) per batch
+        f32x4 av[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long jb = 16L * min(kb + j, b1 - 1);           // clamped + unconditional
+            av[j] = *reinterpret_cast<const f32x4*>(Ap + jb * NFA);
+            bv[j] = *reinterpret_cast<const f32x4*>(Bp + jb * NFB);
+        }
+        __builtin_amdgcn_sched_barrier(0);                       // all sixteen requested before the first select
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool kin = (kb + j) < b1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                av[j][e] = ones ? 1.0f : av[j][e];
+                bv[j][e] = kin ? bv[j][e] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                MFMA16(av[4 * jj + 0][e], bv[4 * jj + 0][e], acc0); MFMA16(av[4 * jj + 1][e], bv[4 * jj + 1][e], acc1);
+                MFMA16(av[4 * jj + 2][e], bv[4 * jj + 2][e], acc2); MFMA16(av[4 * jj + 3][e], bv[4 * jj + 3][e], acc3);
+            }
+    }
+    float* G = a.G + (long)blockIdx.y * a.slab_stride;
+    const int col = n0 + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 4 * q + r;                          // row == fi is the bias
+        if (live && row <= fi && col < fo)
+            G[T.off + (long)row * T.ld + col] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+    }
+}
+
+void launch_fused_dw_slab(hipStream_t s, const DwSlabArgs& a, int splits) {
+    SMRT_LAUNCH(fused_dw_slab_kernel, dim3(dw_opt_blocks(a.total_tiles), splits), dim3(BTHREADS), 0, s, a);
+}
+
 // flat parameter buffer -> LDS-image twin (after set_params, after a per-layer-path update, or from the
 // post-dropout weights every step)
 __global__ __launch_bounds__(256) void build_image_kernel(const float* __restrict__ Wflat, const int* __restrict__ tab,

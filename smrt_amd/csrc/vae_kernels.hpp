@@ -202,6 +202,12 @@ struct DwOptArgs {
     float lr, l2, gmin, gmax, keep;
 };
 void launch_fused_dw_opt(hipStream_t s, const DwOptArgs& a);
+struct DwSlabArgs {            // weight-gradient tiles of a row range into gradient slabs (fused path, larger mini-batches)
+    const DwTile* tiles;
+    int total_tiles, rows, blocks_per_split;
+    float* G; long slab_stride;
+};
+void launch_fused_dw_slab(hipStream_t s, const DwSlabArgs& a, int splits);
 int  dw_opt_blocks(int total_tiles);
 int  fused_set_max_lds(int bytes);
 void launch_build_image(hipStream_t s, const float* Wflat, const int* tab, float* img, int n_f4);

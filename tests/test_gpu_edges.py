@@ -41,6 +41,26 @@ def test_small_batch_to_tiled_kernel_boundary(rows):
     h.close()
 
 
+@pytest.mark.parametrize("rows,opt", [(513, "rms_prop"), (2000, "rms_prop"), (4096, "sgd"), (8192, "rms_prop"), (8193, "rms_prop")])
+def test_fused_net_beyond_512_rows(rows, opt):
+    """A net that fits in LDS keeps the fused forward/backward kernel up to 8192 rows (weight gradients by row range into
+    slabs, then the optimizer sweep); 8193 rows take the per-layer kernels.  Two steps each, so the rebuilt weight image
+    of the second step is covered, then a ragged one."""
+    rs = np.random.RandomState(rows)
+    D, hidden, Z = 40, [72], 6
+    o, h = _pair(D, hidden, Z, "sigmoid", opt, rows, rs)
+    for b in (rows, rows, rows - 300):
+        X, eps = rs.uniform(0, 1, size=(b, D)), rs.normal(size=(b, Z))
+        c_o, (gW, gb) = o.train_step(X, eps, return_grads=True)
+        c_h, g_h = h.train_step(X, eps, want_grads=True)
+        assert np.isclose(c_h, c_o, rtol=1e-4), (b, c_h, c_o)
+        _close(g_h, np.concatenate([np.concatenate([w.ravel(), b_.ravel()]) for w, b_ in zip(gW, gb)]), "gradients %d" % b)
+        if 512 < b <= 8192:
+            assert h.last_epoch_launches <= 6, h.last_epoch_launches     # image, fwd/bwd, slab dW, optimizer, finalize
+    _close(h.get_params(), flatten_params(o.params), "params")
+    h.close()
+
+
 @pytest.mark.parametrize("rows,D,hid", [(3000, 1024, 1000), (6200, 1000, 520)])
 def test_three_tile_shapes_of_the_tiled_gemm(rows, D, hid):
     """The LDS-tiled GEMM picks 128x128, 128x64 or 64x64 tiles by grid size (vae_kernels.hip: tile_sel).  These two
