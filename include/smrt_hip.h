@@ -197,6 +197,7 @@ int  smrt_smote_rows_f64(const double* X_dev, int64_t n_x, int64_t ldx, int64_t 
  *   smrt_diag_step_floor    : a captured graph of steps x kernels_per_step dependent one-word kernels of
  *                             `workgroups` x `threads` -> microseconds per step with no arithmetic at all. */
 int  smrt_diag_mfma_peak(int32_t device, double* tflops);
+int  smrt_diag_mfma_peak_16x16x4(int32_t device, double* tflops);   /* the same loop on v_mfma_f32_16x16x4_f32 */
 int  smrt_diag_hbm_bandwidth(int32_t device, int64_t bytes, double* copy_gbs, double* read_gbs);
 int  smrt_diag_step_floor(int32_t device, int32_t kernels_per_step, int32_t steps, int32_t workgroups,
                           int32_t threads, double* us_per_step);

@@ -27,7 +27,7 @@ EXPORTS = [
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
-    "smrt_assemble_rows", "smrt_assemble_rows_part", "smrt_assemble_rows_f64", "smrt_all_finite", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
+    "smrt_assemble_rows", "smrt_assemble_rows_part", "smrt_assemble_rows_f64", "smrt_all_finite", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_mfma_peak_16x16x4", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
     "smrt_last_error", "smrt_version",
 ]
 
@@ -73,6 +73,7 @@ def load():
     lib.smrt_knn_f64.argtypes = [vp, i64, i64, vp, i64, i64, i64, i32, vp, vp, vp]
     lib.smrt_smote_rows_f64.argtypes = [vp, i64, i64, i64, vp, vp, vp, i64, i32, vp, i64, vp]
     lib.smrt_diag_mfma_peak.argtypes = [i32, dp]
+    lib.smrt_diag_mfma_peak_16x16x4.argtypes = [i32, dp]
     lib.smrt_diag_hbm_bandwidth.argtypes = [i32, i64, dp, dp]
     lib.smrt_diag_step_floor.argtypes = [i32, i32, i32, i32, i32, dp]
     lib.smrt_vae_destroy.restype = None
@@ -151,6 +152,14 @@ def diag_mfma_peak(device=0):
     _torch()
     out = C.c_double()
     _check(load().smrt_diag_mfma_peak(int(device), C.byref(out)), "smrt_diag_mfma_peak")
+    return out.value
+
+
+def diag_mfma_peak_16x16x4(device=0):
+    """The same register-resident loop on v_mfma_f32_16x16x4_f32, the shape of the LDS-resident small-net kernels."""
+    _torch()
+    out = C.c_double()
+    _check(load().smrt_diag_mfma_peak_16x16x4(int(device), C.byref(out)), "smrt_diag_mfma_peak_16x16x4")
     return out.value
 
 

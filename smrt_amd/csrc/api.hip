@@ -68,7 +68,7 @@ struct smrt_vae {
     float* cost_dev = nullptr; long cost_cap = 0;
     float* cost_pin = nullptr; long cost_pin_cap = 0;
 
-    long icap = 0;
+    long icap = 0, izcap = 0;
     float* ibuf[2] = {nullptr, nullptr};
     float* izb = nullptr;
 
@@ -360,12 +360,19 @@ static int ensure_train(smrt_vae* h, int rows) {
     return 0;
 }
 
-static int ensure_infer(smrt_vae* h, long rows) {
-    if (rows <= h->icap) return 0;
-    TRY(dalloc(&h->ibuf[0], (size_t)rows * h->maxld, h->stream));
-    TRY(dalloc(&h->ibuf[1], (size_t)rows * h->maxld, h->stream));
-    TRY(dalloc(&h->izb, (size_t)rows * rup4(h->Z), h->stream));
-    h->icap = rows;
+// Inference buffers: the latent chunk `izb` (generate) and, for the per-layer path only, two ping-pong activation chunks.
+static int ensure_infer(smrt_vae* h, long rows, bool need_ibuf = true) {
+    if (rows > h->izcap) {
+        HIPC(hipStreamSynchronize(h->stream));
+        TRY(dalloc(&h->izb, (size_t)rows * rup4(h->Z), h->stream));
+        h->izcap = rows;
+    }
+    if (need_ibuf && rows > h->icap) {
+        HIPC(hipStreamSynchronize(h->stream));
+        TRY(dalloc(&h->ibuf[0], (size_t)rows * h->maxld, h->stream));
+        TRY(dalloc(&h->ibuf[1], (size_t)rows * h->maxld, h->stream));
+        h->icap = rows;
+    }
     return 0;
 }
 
@@ -1038,6 +1045,46 @@ int smrt_vae_profile_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_
 }
 
 static const long INFER_CHUNK = 32768;
+static const long INFER_CHUNK_FUSED = 1L << 20;      // rows of z drawn per launch on the fused path
+
+// Layers [l0, l1] of a net on the fused path in ONE persistent launch (fused_infer_kernel).  Returns 1 when the launch was
+// enqueued, 0 when this net / call does not qualify (the caller then runs the per-layer GEMM chain), < 0 on error.
+static int infer_fused(smrt_vae* h, int l0, int l1, const float* in, long ldin, long n,
+                       float* out0, long ld0, int split, float* out1, long ld1) {
+    if (!h->fused || !h->Wimg || n <= 0) return 0;
+    const char* e = std::getenv("SMRT_HIP_FUSED_INFER");
+    if (e && std::atoi(e) == 0) return 0;
+    InferArgs a{};
+    const int start = h->flay[l0].lds_w;
+    const int end = h->flay[l1].lds_b + 4 * rup16(h->flay[l1].fo);
+    int maxw = rup16(h->flay[l0].fi);
+    for (int l = l0; l <= l1; ++l) {
+        const FusedLayer& q = h->flay[l];
+        InferStage& t = a.st[a.n_stages++];
+        t.K16 = rup16(q.fi); t.N = q.fo; t.N16 = rup16(q.fo); t.w_off = q.lds_w - start; t.nn = q.nn;
+        t.b_off = q.lds_b - start; t.act = q.act;
+        maxw = std::max(maxw, t.N16);
+    }
+    a.maxt = maxw / 16;
+    if (a.maxt > 8) return 0;                                        // wider layers keep the per-layer chain
+    a.tile_stride = std::max(rup16(h->flay[l0].fi), rup16(h->flay[l1].fo)) + 4;
+    a.img = h->Wimg + start; a.img_n4 = (end - start) / 4;
+    a.in = in; a.ldin = ldin; a.K = h->flay[l0].fi; a.n = n;
+    a.out0 = out0; a.ld0 = ld0; a.split = split; a.out1 = out1; a.ld1 = ld1;
+    const int N = h->flay[l1].fo;
+    a.vec_out = (split >= N && N % 4 == 0 && ld0 % 4 == 0 && ((uintptr_t)out0 & 15) == 0) ? 1 : 0;
+    // the image twin must hold W itself: under dropout it follows the post-dropout weights of the last step
+    // (inference runs with keep = 1, autoencoder.py:448) and training rebuilds it every step anyway
+    if (h->has_drop) {
+        launch_build_image(h->stream, h->W, h->stage_tab, h->Wimg, (int)(h->P_int / 4));
+        h->img_valid = false;
+    } else if (!h->img_valid) {
+        launch_build_image(h->stream, h->W, h->stage_tab, h->Wimg, (int)(h->P_int / 4));
+        h->img_valid = true;
+    }
+    if (launch_fused_infer(h->stream, a) != 0) return 0;
+    return 1;
+}
 
 int smrt_vae_encode(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n, float* mu_dev, float* logsig_dev) {
     if (!h || !mu_dev || (!logsig_dev && !h->ae)) return fail(-1, "smrt_vae_encode: null argument");
@@ -1045,6 +1092,11 @@ int smrt_vae_encode(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n, flo
     if (n == 0) return 0;
     TRY(check_mat(X_dev, ldx, h->D, "smrt_vae_encode: X"));
     HIPC(hipSetDevice(h->device));
+    if (!h->ae) {
+        const int f = infer_fused(h, 0, h->L, X_dev, ldx, n, mu_dev, h->Z, h->Z, logsig_dev, h->Z);
+        if (f < 0) return f;
+        if (f) { HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(h->stream)); return 0; }
+    }
     const long chunk = std::min<long>(n, INFER_CHUNK);
     TRY(ensure_infer(h, chunk));
     for (long r0 = 0; r0 < n; r0 += chunk) {
@@ -1096,6 +1148,11 @@ int smrt_vae_decode(smrt_vae* h, const float* Z_dev, int64_t ldz, int64_t n, flo
     TRY(check_mat(Z_dev, ldz, h->Zc, "smrt_vae_decode: Z"));
     if (ldo < h->D) return fail(-1, "smrt_vae_decode: ldo must be >= n_features");
     HIPC(hipSetDevice(h->device));
+    {
+        const int f = infer_fused(h, h->dec0, h->NL - 1, Z_dev, ldz, n, out_dev, ldo, h->D, nullptr, 0);
+        if (f < 0) return f;
+        if (f) { HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(h->stream)); return 0; }
+    }
     const long chunk = std::min<long>(n, INFER_CHUNK);
     TRY(ensure_infer(h, chunk));
     for (long r0 = 0; r0 < n; r0 += chunk) {
@@ -1115,14 +1172,25 @@ int smrt_vae_generate(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc,
     if (h->ae) return fail(-1, "smrt_vae_generate: a plain auto-encoder has no generative prior");
     if (ldo < h->D) return fail(-1, "smrt_vae_generate: ldo must be >= n_features");
     HIPC(hipSetDevice(h->device));
-    const long chunk = std::min<long>(n, INFER_CHUNK);
-    TRY(ensure_infer(h, chunk));
     const long ldz = rup4(h->Z);
+    const bool fused_ok = h->fused && h->Wimg;
+    const long chunk = std::min<long>(n, fused_ok ? INFER_CHUNK_FUSED : INFER_CHUNK);
+    TRY(ensure_infer(h, chunk, !fused_ok));
     for (long r0 = 0; r0 < n; r0 += chunk) {
-        const int rows = (int)std::min<long>(chunk, n - r0);
+        const long rows = std::min<long>(chunk, n - r0);
         launch_sample_normal(h->stream, h->izb, ldz, rows, h->Z, h->cfg.seed, 3u, 0u,
                              philox_offset + (uint64_t)r0 * h->Z, loc, scale);
-        TRY(decode_chunk(h, h->izb, ldz, rows, out_dev + r0 * ldo, ldo));
+        int f = 0;
+        if (fused_ok) f = infer_fused(h, h->dec0, h->NL - 1, h->izb, ldz, rows, out_dev + r0 * ldo, ldo, h->D, nullptr, 0);
+        if (f < 0) return f;
+        if (!f) {
+            // (only reached when the fused launch was refused: the z chunk is cut to the per-layer path's buffers)
+            TRY(ensure_infer(h, std::min<long>(rows, INFER_CHUNK), true));
+            for (long c0 = 0; c0 < rows; c0 += INFER_CHUNK) {
+                const int cr = (int)std::min<long>(INFER_CHUNK, rows - c0);
+                TRY(decode_chunk(h, h->izb + c0 * ldz, ldz, cr, out_dev + (r0 + c0) * ldo, ldo));
+            }
+        }
     }
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(h->stream));

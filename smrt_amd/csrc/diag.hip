@@ -36,6 +36,22 @@ __global__ void __launch_bounds__(256) diag_mfma_kernel(float* sink, int iters) 
     if (s == 12345.678f) sink[0] = s;                       // keeps the loop alive; practically never taken
 }
 
+// The same loop on v_mfma_f32_16x16x4_f32 (the shape the LDS-resident small-net kernels use): 4 x 2048 FLOP per iteration.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) diag_mfma16_kernel(float* sink, int iters) {
+    v4f acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
+    float a = 1.0f + 0.001f * threadIdx.x, b = 0.5f - 0.001f * threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, a, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, b, acc3, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 4; ++r) s += acc0[r] + acc1[r] + acc2[r] + acc3[r];
+    if (s == 12345.678f) sink[0] = s;
+}
+
 __global__ void __launch_bounds__(256) diag_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
@@ -74,7 +90,7 @@ static float best_ms(hipStream_t s, int reps, const std::function<hipError_t()>&
     return best;
 }
 
-extern "C" int smrt_diag_mfma_peak(int32_t device, double* tflops) {
+static int mfma_peak(int32_t device, bool small_shape, double* tflops) {
     if (!tflops) return smrt_set_error(-1, "smrt_diag_mfma_peak: null output");
     DIAGC(hipSetDevice(device));
     hipDeviceProp_t prop;
@@ -87,15 +103,19 @@ extern "C" int smrt_diag_mfma_peak(int32_t device, double* tflops) {
     const int blocks = prop.multiProcessorCount * 2;         // 2 x 4 waves per CU: two waves per SIMD
     hipError_t err = hipSuccess;
     const float ms = best_ms(s, 4, [&]() {
-        hipLaunchKernelGGL(diag_mfma_kernel, dim3(blocks), dim3(256), 0, s, sink, iters);
+        if (small_shape) hipLaunchKernelGGL(diag_mfma16_kernel, dim3(blocks), dim3(256), 0, s, sink, iters);
+        else hipLaunchKernelGGL(diag_mfma_kernel, dim3(blocks), dim3(256), 0, s, sink, iters);
         return hipGetLastError();
     }, &err);
     (void)hipFree(sink); (void)hipStreamDestroy(s);
     if (err != hipSuccess) return smrt_set_error(-2, std::string("smrt_diag_mfma_peak: ") + hipGetErrorString(err));
-    const double flop = (double)blocks * 4 /*waves*/ * iters * 4.0 * (2.0 * 32 * 32 * 2);
+    const double flop = (double)blocks * 4 /*waves*/ * iters * 4.0 * (small_shape ? 2.0 * 16 * 16 * 4 : 2.0 * 32 * 32 * 2);
     *tflops = flop / (ms * 1e-3) / 1e12;
     return 0;
 }
+
+extern "C" int smrt_diag_mfma_peak(int32_t device, double* tflops) { return mfma_peak(device, false, tflops); }
+extern "C" int smrt_diag_mfma_peak_16x16x4(int32_t device, double* tflops) { return mfma_peak(device, true, tflops); }
 
 extern "C" int smrt_diag_hbm_bandwidth(int32_t device, int64_t bytes, double* copy_gbs, double* read_gbs) {
     if (bytes < (1 << 20) || !copy_gbs || !read_gbs) return smrt_set_error(-1, "smrt_diag_hbm_bandwidth: bad arguments");

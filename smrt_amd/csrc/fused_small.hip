@@ -673,6 +673,177 @@ void launch_build_image(hipStream_t s, const float* Wflat, const int* tab, float
     SMRT_LAUNCH(build_image_kernel, dim3((n_f4 + 255) / 256), dim3(256), 0, s, Wflat, tab, img, n_f4);
 }
 
+// =====================================================================================
+// Inference through a chain of dense layers (encode: X -> [mu | log_sigma], autoencoder.py:488-500; decode / generate:
+// z -> decoder, autoencoder.py:502-517,549-572) for nets on the fused path.  The layer-by-layer GEMM chain writes every
+// intermediate to HBM and reads it back, one launch per layer and 32 768-row chunk; here ONE persistent launch does it:
+//   * a workgroup stages the image of the layers it needs (a contiguous range of the LDS-image twin) once;
+//   * then every WAVE owns 16 rows at a time and carries them through all layers on its own, with the activations in
+//     REGISTERS: the product is computed transposed, Y^T = W^T . X^T (weights are the MFMA A operand, the 16 rows the B
+//     operand), so lane (c, q) ends up with Y[row c][16 t + 4 q + r] in register r of output tile t -- which is exactly
+//     the B fragment of k-block t of the next layer (same k permutation inside a 16-block as everywhere in this file).
+//     No transpose, no LDS traffic for activations, no barrier after the staging; the only LDS reads are the weight
+//     fragments (one ds_read_b128 per four MFMAs).
+// HBM traffic is the algorithmic 4 (K + N) bytes per row.  Layers up to 128 wide (IMAXT 16-column tiles); wider nets on
+// the fused path keep the per-layer chain.
+// =====================================================================================
+constexpr int IMAXT = 8;               // activations up to 128 wide
+constexpr int ITHREADS = 512;          // 8 waves in ONE workgroup per CU (2 per SIMD, up to 256 VGPRs each).  Several smaller workgroups per CU
+                                       // were slower: a persistent grid is not spread evenly over the CUs by the dispatcher
+
+// One layer for one wave, all NN output tiles at once: acc[t] starts at the bias, and for every 16-wide k-block the NN
+// weight fragments are requested in one batch and multiplied into NN independent accumulators (consecutive MFMAs never
+// depend on each other once NN >= 2).  The outputs overwrite `cur` in place -- they are the next layer's B fragments.
+template <int NN>
+__device__ __forceinline__ void infer_layer(const float* lds, f32x4 (&cur)[IMAXT], int nK, int N, int w_off, int nn,
+                                            int b_off, int act, int c, int q, bool to_tile, float* tile, int s_t) {
+    f32x4 acc[NN];
+#pragma unroll
+    for (int t = 0; t < NN; ++t) {
+        const float* bb = lds + b_off + 4 * (16 * t + 4 * q);             // bias image: b[col] at 4 * col, rup16(fan_out) entries
+        acc[t] = f32x4{bb[0], bb[4], bb[8], bb[12]};
+    }
+    const float* wp = lds + w_off + ((q * nn + c) << 2);
+    const int bstep = nn << 4;
+#pragma unroll
+    for (int j = 0; j < IMAXT; ++j) {
+        if (j < nK) {                                                      // uniform; the block below is straight-line
+            f32x4 w[NN];
+#pragma unroll
+            for (int t = 0; t < NN; ++t) w[t] = *reinterpret_cast<const f32x4*>(wp + j * bstep + 64 * t);
+            __builtin_amdgcn_sched_barrier(0);                             // all NN reads requested before the first MFMA
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NN; ++t) MFMA16(w[t][e], cur[j][e], acc[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NN; ++t) {
+        float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+        act_fwd4(act, v);                                                  // y = act(x.W + b), layer.py:368
+        const int col0 = 16 * t + 4 * q;
+        if (to_tile) {
+            *reinterpret_cast<f32x4*>(tile + c * s_t + col0) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            // pad columns must be finite zeros: they meet the zero rows of the next layer's image
+            if (16 * t + 16 <= N) cur[t] = f32x4{v[0], v[1], v[2], v[3]};      // (uniform: only a ragged last tile is masked)
+            else cur[t] = f32x4{col0 < N ? v[0] : 0.f, col0 + 1 < N ? v[1] : 0.f, col0 + 2 < N ? v[2] : 0.f, col0 + 3 < N ? v[3] : 0.f};
+        }
+    }
+}
+
+__global__ __launch_bounds__(ITHREADS) void fused_infer_kernel(const InferArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = UNI(tid >> 6);
+    const int c = lane & 15, q = lane >> 4;
+    {
+        const float4* src = reinterpret_cast<const float4*>(a.img);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = tid; i < a.img_n4; i += ITHREADS) dst[i] = src[i];
+    }
+    __syncthreads();
+    const long nblk = (a.n + 15) >> 4;
+    const long wstride = (long)gridDim.x * (ITHREADS / 64);
+    const int K = a.K, nK0 = a.st[0].K16 >> 4, k4n = a.st[0].K16 >> 2, last = a.n_stages - 1, Nl = a.st[last].N;
+    const int s_t = a.tile_stride;
+    float* tile = lds + 4 * a.img_n4 + wave * (16 * s_t);
+#pragma unroll 1
+    for (long blk = (long)blockIdx.x * (ITHREADS / 64) + wave; blk < nblk; blk += wstride) {   // wave-uniform
+        const long r0 = blk << 4;
+        // Rows enter and leave through a wave-private LDS tile so that global traffic is whole rows (16 bytes per lane,
+        // consecutive lanes along a row).  Rows past the end shadow the last row (never stored), columns past K are zero.
+        // (no integer division: a row takes 4 or 16 lanes, whichever the row length fills)
+        {
+            const int sh = (k4n >= 16) ? 4 : 2, lpr = 1 << sh, rpi = 64 >> sh;         // lanes per row, rows per instruction
+            const int lr = lane >> sh, lc = lane & (lpr - 1);
+            for (int rr = 0; rr < 16; rr += rpi) {
+                const int r = rr + lr;
+                const float* src = a.in + min(r0 + r, a.n - 1) * a.ldin;
+                for (int m = lc; m < k4n; m += lpr) {
+                    const int c4 = m << 2;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (c4 < K) v = *reinterpret_cast<const f32x4*>(src + c4);             // c4 + 3 < rup4(K) <= ldin
+                    v[1] = (c4 + 1 < K) ? v[1] : 0.f; v[2] = (c4 + 2 < K) ? v[2] : 0.f; v[3] = (c4 + 3 < K) ? v[3] : 0.f;
+                    *reinterpret_cast<f32x4*>(tile + r * s_t + c4) = v;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");             // written by other lanes of this wave
+        __builtin_amdgcn_wave_barrier();
+        f32x4 cur[IMAXT];
+#pragma unroll
+        for (int j = 0; j < IMAXT; ++j) {
+            cur[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < nK0) cur[j] = *reinterpret_cast<const f32x4*>(tile + c * s_t + 16 * j + 4 * q);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int s = 0; s <= last; ++s) {
+            const int nK = UNI(a.st[s].K16) >> 4, N = UNI(a.st[s].N), nN = UNI(a.st[s].N16) >> 4, w_off = UNI(a.st[s].w_off),
+                      nn = UNI(a.st[s].nn), b_off = UNI(a.st[s].b_off), act = UNI(a.st[s].act);
+            const bool tt = (s == last);
+            switch (nN) {
+                case 1: infer_layer<1>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
+                case 2: infer_layer<2>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
+                case 3: infer_layer<3>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
+                case 4: infer_layer<4>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
+                case 5: infer_layer<5>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
+                case 6: infer_layer<6>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
+                case 7: infer_layer<7>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
+                default: infer_layer<8>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // the tile holds the last layer's [16][N] block
+        if (a.vec_out) {
+            const int n4 = Nl >> 2;
+            const int sh = (n4 >= 16) ? 4 : 2, lpr = 1 << sh, rpi = 64 >> sh;
+            const int lr = lane >> sh, lc = lane & (lpr - 1);
+            for (int rr = 0; rr < 16; rr += rpi) {
+                const int r = rr + lr;
+                if (r0 + r < a.n) {
+                    float* dst = a.out0 + (r0 + r) * a.ld0;
+                    for (int m = lc; m < n4; m += lpr)
+                        *reinterpret_cast<f32x4*>(dst + 4 * m) = *reinterpret_cast<const f32x4*>(tile + r * s_t + 4 * m);
+                }
+            }
+        } else {
+            const int lr = lane >> 4, lc = lane & 15;
+            for (int rr = 0; rr < 16; rr += 4) {
+                const int r = rr + lr;
+                if (r0 + r < a.n) {
+                    for (int k = lc; k < Nl; k += 16) {
+                        const float v = tile[r * s_t + k];
+                        if (k < a.split) a.out0[(r0 + r) * a.ld0 + k] = v;
+                        else a.out1[(r0 + r) * a.ld1 + (k - a.split)] = v;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");             // the tile is rewritten by the next block of rows
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_fused_infer(hipStream_t s, const InferArgs& a) {
+    const int lds_bytes = a.img_n4 * 16 + (ITHREADS / 64) * 16 * a.tile_stride * (int)sizeof(float);
+    if (a.maxt > IMAXT || lds_bytes > 160 * 1024) return -1;               // the caller takes the per-layer path
+    if (lds_bytes > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fused_infer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    const long nblk = (a.n + 15) >> 4;
+    const long wgs = (nblk + ITHREADS / 64 - 1) / (ITHREADS / 64);
+    SMRT_LAUNCH(fused_infer_kernel, dim3((unsigned)std::min<long>(wgs, 256)), dim3(ITHREADS), (size_t)lds_bytes, s, a);
+    return 0;
+}
+
 int dw_opt_blocks(int total_tiles) { return (total_tiles + 3) / 4; }
 
 void launch_fused_dw_opt(hipStream_t s, const DwOptArgs& a) {

@@ -208,6 +208,20 @@ struct DwSlabArgs {            // weight-gradient tiles of a row range into grad
     float* G; long slab_stride;
 };
 void launch_fused_dw_slab(hipStream_t s, const DwSlabArgs& a, int splits);
+// Fused inference (encode / decode / generate) for nets whose weights fit in LDS: fused_small.hip
+struct InferStage { int K16, N, N16, w_off, nn, b_off, act, pad; };   // image offsets relative to the staged range
+struct InferArgs {
+    InferStage st[MAX_LAYERS]; int n_stages;
+    const float* img; int img_n4;         // staged range of the LDS-image twin: img_n4 16-byte pieces to LDS offset 0
+    const float* in; long ldin; int K;    // input rows, row-major; K valid columns
+    long n;                               // rows
+    float* out0; long ld0; int split;     // output columns [0, split) -> out0, [split, N) -> out1 (encode: mu | log_sigma)
+    float* out1; long ld1;
+    int vec_out;                          // out0 takes whole 16-byte stores (split == N, N % 4 == 0, ld0 % 4 == 0, aligned)
+    int tile_stride;                      // floats per row of the wave-private I/O tile: max(rup16(K), rup16(N_last)) + 4
+    int maxt;                             // widest activation of the chain in 16-column tiles (kernel variant: 8 or 16)
+};
+int  launch_fused_infer(hipStream_t s, const InferArgs& a);
 int  dw_opt_blocks(int total_tiles);
 int  fused_set_max_lds(int bytes);
 void launch_build_image(hipStream_t s, const float* Wflat, const int* tab, float* img, int n_f4);

@@ -329,3 +329,40 @@ def test_fast_generate_stream():
     z = 0.5 + 2.0 * philox_normal(77, STREAM_GENERATE, 0, 12, 50 * Z).reshape(50, Z)
     _close(got, o.decode(z), "fast generate")
     h.close()
+
+
+@pytest.mark.parametrize("D,hidden,Z,act,drop", [
+    (64, [128], 16, "sigmoid", 1.0),        # the bench net N2: whole 16-byte row stores
+    (67, [45, 130], 9, "tanh", 1.0),        # odd widths: element-wise stores, two encoder / three decoder layers
+    (30, [24], 10, "elu", 0.5),             # dropout: the image twin is rebuilt from W (inference runs with keep = 1)
+])
+def test_fused_inference_launch_matches_oracle(D, hidden, Z, act, drop, kernel_path, monkeypatch):
+    """encode / decode / generate of a net on the fused path run as ONE persistent launch (fused_infer_kernel: a wave
+    carries 16 rows through every layer in LDS).  Checked against the oracle at row counts that leave a ragged last
+    16-row block and give some waves several blocks, after a training step (image kept current by the optimizer
+    epilogue), and against the per-layer GEMM chain on the same handle."""
+    rs = np.random.RandomState(23)
+    o = _oracle(D, hidden, Z, act=act, drop=drop, rs=rs)
+    h = _handle(D, hidden, Z, act=act, drop=drop, max_batch=64)
+    h.set_params(flatten_params(o.params))
+    if drop == 1.0:
+        X, eps = rs.uniform(0, 1, size=(64, D)), rs.normal(size=(64, Z))
+        o.train_step(X, eps); h.train_step(X, eps)
+    for n in (1, 16, 37, 5003):
+        Xe, Zs = rs.uniform(0, 1, size=(n, D)), rs.normal(size=(n, Z))
+        mu, ls = h.encode(Xe)
+        mu_o, ls_o = o.encode(Xe)
+        _close(mu, mu_o, "mu n=%d" % n); _close(ls, ls_o, "log_sigma n=%d" % n)
+        dec = h.decode(Zs)
+        _close(dec, o.decode(Zs), "decode n=%d" % n)
+        if kernel_path == "fused":
+            monkeypatch.setenv("SMRT_HIP_FUSED_INFER", "0")        # same handle, per-layer GEMM chain
+            mu2, ls2 = h.encode(Xe)
+            dec2 = h.decode(Zs)
+            monkeypatch.delenv("SMRT_HIP_FUSED_INFER")
+            _close(mu, mu2, "mu vs per-layer", rtol=1e-5); _close(ls, ls2, "log_sigma vs per-layer", rtol=1e-5)
+            _close(dec, dec2, "decode vs per-layer", rtol=1e-5)
+    got = h.generate(4099, philox_offset=3, loc=0.25, scale=1.5)
+    z = 0.25 + 1.5 * philox_normal(42, STREAM_GENERATE, 0, 3, 4099 * Z).reshape(4099, Z)
+    _close(got, o.decode(z), "generate")
+    h.close()
