@@ -10,7 +10,7 @@ i.e. one pass of the hot path over the batch of synthetic input; value = rows tr
 With --gpus N every rank trains its own minority-class job (the per-class jobs of smrt_balance
 are independent: weak scaling, no collective on the data path).
 
-After the timed region (outside `value`) two end-to-end legs run at every N under a watchdog (--legs-timeout):
+After the timed region (outside `value`) the generation half (`generate_c2`, N = 1) and two end-to-end legs run at every N under a watchdog (--legs-timeout):
 `smrt_balance_c3` (config C3: 8 per-class fit -> generate jobs sharded over the ranks, no data-path collective) and
 `dp_c4` (config C4, scaled: ONE class trained data-parallel, all_reduce of the gradients per mini-batch over RCCL).
 
@@ -368,6 +368,23 @@ def main():
             out["latency_floor"] = {"kernels_per_minibatch": k_per_mb, "us_per_minibatch": floor_us,
                                     "ms_per_step": floor_us * steps_per_epoch / 1e3,
                                     "frac_of_step": floor_us * steps_per_epoch / 1e3 / out["ms_per_step"]}
+        if world == 1 and not args.no_diag:
+            # The generation half of the path (176 470 synthetic rows from the trained decoder), outside
+            # `value`: one persistent launch (fused_infer_kernel) behind the Philox draw of z; wall-clock per call with
+            # the output resident in HBM.  2 P_dec FLOP and 4 (Z + D) bytes per row.
+            n_gen, reps = 176470, 10
+            sess.generate(n_gen, to_host=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(reps):
+                sess.generate(n_gen, philox_offset=i * n_gen * Z, to_host=False)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            p_dec = Z * HIDDEN[-1] + sum(a * b for a, b in zip(HIDDEN[::-1], HIDDEN[::-1][1:] + [D]))
+            out["generate_c2"] = {"rows": n_gen, "ms": 1e3 * dt, "rows_per_s": n_gen / dt,
+                                  "tflops": n_gen / dt * 2 * p_dec / 1e12,
+                                  "mfma_frac": n_gen / dt * 2 * p_dec / 1e12 / PEAK_MFMA_F32_TFLOPS,
+                                  "gbs": n_gen / dt * 4 * (Z + D) / 1e9, "hbm_frac": n_gen / dt * 4 * (Z + D) / 1e9 / PEAK_HBM_GBS}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X)
         if world == 1 and not args.no_balance:
