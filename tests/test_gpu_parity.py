@@ -366,3 +366,19 @@ def test_fused_inference_launch_matches_oracle(D, hidden, Z, act, drop, kernel_p
     z = 0.25 + 1.5 * philox_normal(42, STREAM_GENERATE, 0, 3, 4099 * Z).reshape(4099, Z)
     _close(got, o.decode(z), "generate")
     h.close()
+
+
+def test_generate_across_z_chunks_is_position_independent():
+    """smrt_vae_generate draws z in chunks (1 Mi rows on the fused path, 32 768 on the per-layer path); row r uses the
+    Philox elements philox_offset + r * Z ..., whatever chunk or 16-row block it falls in.  Full-size property: the rows
+    either side of every chunk boundary of one big call equal small calls that start at those rows."""
+    import torch
+    D, hidden, Z = 64, [128], 16
+    n = (1 << 20) + 37
+    h = _handle(D, hidden, Z, seed=5, max_batch=128)
+    big = h.generate(n, philox_offset=11, to_host=False)
+    for start, cnt in ((0, 50), (32768 - 20, 40), ((1 << 20) - 20, 57)):
+        part = h.generate(cnt, philox_offset=11 + start * Z, to_host=False)
+        assert torch.equal(big[start:start + cnt], part), "rows %d.." % start
+    assert bool(torch.isfinite(big).all())
+    h.close()
