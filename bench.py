@@ -70,21 +70,37 @@ def kind_work(rows_per_epoch, steps_per_epoch):
     }
 
 
-def measured_traffic(kind):
-    """HBM bytes per launch of kernel `kind` from the newest committed PMC summary (profiles/*_traffic.json, written
-    by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command;
-    FETCH_SIZE doubled per MI355X_MICROARCH.md).  None when no summary names the kernel."""
+def csrc_hash():
+    """sha256 over the kernel sources: the stamp tools/pmc_traffic.py puts into a traffic summary, so that a summary
+    measured on other kernels than the ones built now is recognised as stale."""
     import glob
-    best = None
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "smrt_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(kind):
+    """(HBM bytes per launch of kernel `kind`, stale flag) from the committed PMC summaries (profiles/*_traffic.json,
+    written by tools/pmc_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md).  Only a summary stamped with the hash of the kernel sources as they are
+    NOW counts: counters cannot be collected inside this run, and a figure measured on other kernels is not reported --
+    then (None, True)."""
+    import glob
+    want, best, any_named = csrc_hash(), None, False
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
         try:
-            ks = json.load(open(path)).get("kernels", {})
+            doc = json.load(open(path))
         except Exception:
             continue
-        for name, rec in ks.items():
+        for name, rec in doc.get("kernels", {}).items():
             if name.startswith(kind):
-                best = float(rec["hbm_bytes_per_launch"])
-    return best
+                any_named = True
+                if doc.get("csrc_hash") == want:
+                    best = float(rec["hbm_bytes_per_launch"])
+    return best, (best is None and any_named)
 
 
 def cpu_baseline(X, seconds_budget=12.0):
@@ -251,6 +267,30 @@ def note(rank, what):
 T_START = time.perf_counter()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here, one child process per GPU, with
+    the environment torch.distributed.run would give them.  The parent never touches the GPU (no re-exec of a process
+    that has initialised HIP), forwards the children's output, and returns the worst exit status: a rank that hangs or
+    dies makes the whole run fail."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    for r, p in enumerate(procs):
+        rc = p.wait()
+        if rc != 0:
+            sys.stderr.write("[bench] rank %d exited with status %d\n" % (r, rc))
+            worst = worst or (rc if rc > 0 else 1)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,10 +303,17 @@ def main():
     ap.add_argument("--no-diag", action="store_true", help="skip the measured-peak / latency-floor kernels (rocprof runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d (launch one rank per GPU, or leave RANK unset and "
+                         "let bench.py start the ranks itself)\n" % (args.gpus, world))
+        sys.exit(2)
     dist = None
     # one rank per GPU; SMRT_BENCH_BACKEND=gloo lets the N > 1 path be rehearsed with several ranks on ONE GPU
     backend = os.environ.get("SMRT_BENCH_BACKEND", "nccl")
@@ -280,6 +327,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from smrt_amd import _hip
     from smrt_amd.autoencode.topography import VAETopography
@@ -338,7 +386,9 @@ def main():
         achieved = w["bytes"] / w["launches"] / (pk["avg_us"] * 1e-6) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": achieved / PEAK_HBM_GBS, "traffic": None}
-    roof["traffic"] = measured_traffic(dom)
+    roof["traffic"], stale = measured_traffic(dom)
+    if stale:
+        roof["traffic_stale"] = True      # profiles/ holds a figure for this kernel, measured on other sources
     roof.update({"kernel": dom, "avg_launch_us": pk["avg_us"], "avg_launch_us_eager": pk["avg_us_eager"],
                  "launches_per_step": pk["launches_per_epoch"],
                  "algorithmic_per_launch": w.get("flops", w.get("bytes")) / w["launches"]})
@@ -403,7 +453,10 @@ def main():
                 out.setdefault("dp_c4", {"error": "timeout"})
                 sys.stdout.write(json.dumps(out) + "\n")
                 sys.stdout.flush()
-            os._exit(0)
+            sys.stderr.write("[bench] rank %d: end-to-end legs timed out after %.0f s -- exiting with status 3\n"
+                             % (rank, args.legs_timeout))
+            sys.stderr.flush()
+            os._exit(3)          # a hang is a failure: the headline line is out, the status says the run was not clean
 
         dog = threading.Timer(args.legs_timeout, bail)
         dog.daemon = True
@@ -434,7 +487,7 @@ def main():
         # the line is out: a rank that does not come back from the closing barrier (a peer died in a leg) must not keep
         # the launcher waiting
         import threading
-        last = threading.Timer(30.0, lambda: os._exit(0))
+        last = threading.Timer(30.0, lambda: os._exit(3))      # a peer never reached the barrier: not a clean run
         last.daemon = True
         last.start()
         dist.barrier()

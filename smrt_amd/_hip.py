@@ -407,9 +407,12 @@ class VaeHandle(object):
         if isinstance(X, tuple):
             return X
         if hasattr(X, "data_ptr"):
-            if X.shape[1] % 4 == 0 and X.is_contiguous():
+            # only an fp32 tensor that already sits on THIS GPU in the kernels' layout is passed through as a pointer;
+            # anything else (CPU tensor, fp64, another device, ragged width) goes through the host conversion
+            if (X.dim() == 2 and X.dtype == _torch().float32 and X.device == self.device and X.shape[1] % 4 == 0
+                    and X.is_contiguous()):
                 return X, X.shape[1]
-            X = X.cpu().numpy()
+            X = X.detach().cpu().numpy()
         return to_device_padded(X, self.device)
 
     def train_step(self, X, eps=None, want_grads=False):
@@ -430,6 +433,7 @@ class VaeHandle(object):
 
     def train_epochs(self, X, batch_size, n_epochs, early_stopping=False, min_change=1e-3):
         Xt, ldx = self._as_dev(X)
+        sync_torch_stream(self.device)
         n = Xt.shape[0]
         costs = np.zeros(max(n_epochs, 1), dtype=np.float32)
         ms = np.zeros(max(n_epochs, 1), dtype=np.float32)

@@ -75,10 +75,13 @@ class DataParallelTrainer(object):
             raise ValueError("rank %d holds %d rows, its stripes need %d" % (rank, X_local[0].shape[0], n_local))
         self.grads = torch.zeros(sess.dp_count, dtype=torch.float32, device=sess.device)
         self.on_gpu = sess.device.type == "cuda"
-        # A host-side backend (gloo) reduces through host memory: it is handed a gradient buffer whose kernels have
-        # finished.  (Measured on MI355X / ROCm 7.2: a gloo all_reduce of a CUDA tensor entered while kernels are still
-        # queued on the current stream never returns; entered after a stream synchronise it takes 10 ms.)  RCCL is ordered
-        # on the stream itself and gets no synchronisation.
+        # A host-side backend (gloo: the one-GPU rehearsal of this loop) reduces HOST tensors here: the gradient buffer is
+        # copied down (a stream-ordered copy that waits for exactly the kernels that wrote it), reduced, and copied back.
+        # gloo is never handed a device tensor.  Round 1 did hand it one and found that a gloo all_reduce of a device
+        # tensor entered while kernels were still queued on the current (legacy) stream never returned on this image; every
+        # launch of the two async halves is on the lent stream (api.hip: enqueue_step / enqueue_apply / the rows == 0
+        # memset all take h->stream), so the wait was inside gloo's own device-tensor path (its worker thread's private
+        # stream against the legacy stream), which this loop no longer enters.  RCCL is ordered on the stream itself.
         self.host_collective = bool(self.on_gpu and dist is not None and self.world > 1 and dist.get_backend() != "nccl")
 
     def run_epochs(self, n_epochs, early_stopping=False, min_change=1e-3):
@@ -101,11 +104,19 @@ class DataParallelTrainer(object):
                     off += rows
                     if dist is not None and self.world > 1:
                         if self.host_collective:
-                            stream.synchronize()
-                        dist.all_reduce(self.grads)                    # SUM; RCCL ring / tree over xGMI under nccl
+                            g_host = self.grads.cpu()
+                            dist.all_reduce(g_host)
+                            self.grads.copy_(g_host)
+                        else:
+                            dist.all_reduce(self.grads)                # SUM; RCCL ring / tree over xGMI under nccl
                     sess.dp_apply(self.grads, cost[ep:ep + 1] if i == len(self.plan) - 1 else None)
-                if early_stopping and dist is not None and self.world > 1:
-                    dist.broadcast(cost[ep:ep + 1], src=0)             # one decision for all ranks
+                if early_stopping and dist is not None and self.world > 1:     # one decision for all ranks
+                    if self.host_collective:
+                        c_host = cost[ep:ep + 1].cpu()
+                        dist.broadcast(c_host, src=0)
+                        cost[ep:ep + 1].copy_(c_host)
+                    else:
+                        dist.broadcast(cost[ep:ep + 1], src=0)
                 c = float(cost[ep].item())                             # the epoch's only host synchronisation
                 seconds.append(time.perf_counter() - t0)
                 costs.append(np.float32(c))

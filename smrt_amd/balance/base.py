@@ -41,7 +41,7 @@ def validate_X_y_ratio_classes(X, y, ratio, copy=True, keep_float32=False):
     if small_ints:
         # non-negative integer labels: one counting pass gives what type_of_target + np.unique (two sorts of y) give --
         # integer targets are 'binary' with up to two distinct values and 'multiclass' beyond (sklearn.utils.multiclass)
-        tally = np.bincount(y)
+        tally = np.bincount(y.astype(np.intp, copy=False))       # (uint64 labels do not cast to intp 'safely'; the range is checked)
         present_classes = np.flatnonzero(tally).astype(y.dtype)
         counts = tally[present_classes]
         kind = "binary" if len(present_classes) <= 2 else "multiclass"

@@ -851,9 +851,19 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     TRY(ensure_train(h, bmax));
     const long nb = (n_rows + batch_size - 1) / batch_size;
     TRY(ensure_cost(h, std::max<long>(n_epochs, 1) + 1));
-    while ((long)h->events.size() < 2L * std::max(n_epochs, 1)) {
+    // a bounded ring of event pairs: at most EV_RING epochs are in flight before the host waits and reads their times
+    constexpr int EV_RING = 64;
+    while ((long)h->events.size() < 2L * std::min(std::max(n_epochs, 1), EV_RING)) {
         hipEvent_t e; HIPC(hipEventCreate(&e)); h->events.push_back(e);
     }
+    std::vector<float> ep_ms((size_t)std::max(n_epochs, 1), 0.f);
+    int harvested = 0;
+    auto harvest = [&](int upto) {                  // epochs [harvested, upto) have completed
+        for (; harvested < upto; ++harvested) {
+            const int k = harvested % EV_RING;
+            (void)hipEventElapsedTime(&ep_ms[harvested], h->events[2 * k], h->events[2 * k + 1]);
+        }
+    };
     if (epochs_done) *epochs_done = 0;
     if (n_epochs == 0) return 0;
     ensure_image(h);
@@ -902,10 +912,15 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     }
     int done = 0; float last_cost = 0.f; bool have_last = false; int rc = 0;
     auto run_epoch = [&](int ep) -> int {
-        HIPC(hipEventRecord(h->events[2 * ep], h->stream));
+        if (ep - harvested >= EV_RING) {            // the ring is full: wait for what is queued, read its times
+            HIPC(hipStreamSynchronize(h->stream));
+            harvest(ep);
+        }
+        const int k = ep % EV_RING;
+        HIPC(hipEventRecord(h->events[2 * k], h->stream));
         if (graphed) HIPC(hipGraphLaunch(h->gexec, h->stream));
         else TRY(enqueue_epoch(h->cost_dev));
-        HIPC(hipEventRecord(h->events[2 * ep + 1], h->stream));
+        HIPC(hipEventRecord(h->events[2 * k + 1], h->stream));
         HIPC(hipMemcpyAsync(h->cost_pin + ep, h->cost_dev, sizeof(float), hipMemcpyDeviceToHost, h->stream));
         return 0;
     };
@@ -928,11 +943,10 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
             else last_cost = c;
         }
     }
+    harvest(done);
     for (int ep = 0; ep < done; ++ep) {
         if (epoch_cost_host) epoch_cost_host[ep] = h->cost_pin[ep];
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, h->events[2 * ep], h->events[2 * ep + 1]);
-        if (epoch_ms_host) epoch_ms_host[ep] = ms;
+        if (epoch_ms_host) epoch_ms_host[ep] = ep_ms[ep];
     }
     h->steps += (int64_t)done * nb;
     if (epochs_done) *epochs_done = done;

@@ -99,7 +99,7 @@ sess = OracleDPSession(o)
 idx = local_row_index(len(X), batch, world, rank)
 Xl = torch.from_numpy(np.ascontiguousarray(X[idx], dtype=np.float32))
 tr = DataParallelTrainer(sess, (Xl, Xl.shape[1]), len(X), batch, rank, world, dist)
-costs, secs = tr.run_epochs(epochs)
+costs, secs = tr.run_epochs(epochs, early_stopping=True, min_change=1e-7)      # broadcast of the cost every epoch
 np.savez(os.path.join(out, "out%d.npz" % rank), costs=costs, params=flatten_params(o.params), n_local=len(idx))
 dist.barrier()
 dist.destroy_process_group()
@@ -126,7 +126,7 @@ def test_dp_host_loop_two_gloo_ranks_equals_single_oracle(tmp_path):
     X = rs.uniform(0, 1, size=(37, 11))
     np.savez(tmp_path / "in.npz", X=X, batch=8, epochs=3)
     ref = OracleVAE(11, [9, 7], 3, activation="tanh", learning_function="adam", learning_rate=0.01, seed=5)
-    ref.fit(X, n_epochs=3, batch_size=8)
+    ref.fit(X, n_epochs=3, batch_size=8, early_stopping=True, min_change=1e-7)
     script = tmp_path / "worker.py"
     script.write_text(CPU_WORKER.format(root=ROOT))
     _run_ranks(script, tmp_path)
@@ -191,7 +191,7 @@ dist.init_process_group("gloo", init_method="tcp://127.0.0.1:" + port, rank=rank
 d = np.load(os.path.join(out, "in.npz"))
 X = d["X"]
 est = VariationalAutoEncoder([48, 32], 6, activation_function="relu", learning_function="adam", learning_rate=0.01,
-                             n_epochs=3, batch_size=256, random_state=7)
+                             n_epochs=3, batch_size=256, random_state=7, early_stopping=True, min_change=1e-7)
 est.data_parallel = True
 est.fit(X)
 np.savez(os.path.join(out, "out%d.npz" % rank), costs=np.asarray(est.epoch_costs_),
@@ -210,7 +210,8 @@ def test_dp_fit_two_ranks_on_one_gpu_equals_single_fit(tmp_path):
     X = rs.uniform(0, 1, size=(1100, 40))                             # batch 256 -> ragged tail of 76
     np.savez(tmp_path / "in.npz", X=X)
     single = VariationalAutoEncoder([48, 32], 6, activation_function="relu", learning_function="adam",
-                                    learning_rate=0.01, n_epochs=3, batch_size=256, random_state=7).fit(X)
+                                    learning_rate=0.01, n_epochs=3, batch_size=256, random_state=7, early_stopping=True,
+                                    min_change=1e-7).fit(X)
     ref_params, ref_costs, ref_gen = single.sess.get_params(), np.asarray(single.epoch_costs_), single.generate(5)
     single.clean_session()
     script = tmp_path / "worker.py"

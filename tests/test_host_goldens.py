@@ -224,3 +224,16 @@ def test_topography_matches_reference():
     assert exc_name(_topo, 5, 10, -1) == ge["latent_negative"]
     assert exc_name(_topo, 5, 10, 2, layer_type="he") == ge["bad_layer_type"]
     assert exc_name(_topo, 5, 10, 2, bias_strategy="twos") == ge["bad_bias"]
+
+
+@pytest.mark.parametrize("dtype", [np.uint64, np.uint8, np.int16])
+def test_small_integer_labels_of_any_integer_dtype(dtype):
+    """The counting fast path takes unsigned 64-bit labels too (np.bincount refuses them uncast) and agrees with the
+    np.unique path the reference takes (smrt/balance/base.py:36-47)."""
+    rs = np.random.RandomState(0)
+    y = np.concatenate([np.zeros(40), np.ones(7), np.full(5, 3)]).astype(dtype)
+    X = rs.uniform(size=(len(y), 4))
+    _, yv, n_classes, present, counts, majority, target = validate_X_y_ratio_classes(X, y, 0.5)
+    u, c = np.unique(y, return_counts=True)
+    assert n_classes == 3 and np.array_equal(present, u) and np.array_equal(counts, c)
+    assert majority == 0 and target == 20 and present.dtype == y.dtype

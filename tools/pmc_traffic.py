@@ -6,8 +6,10 @@
 
 HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE, both counters in KiB as rocprofv3 reports them and
 collected in separate passes; the factor 2 is the gfx950 correction of MI355X_MICROARCH.md ("FETCH_SIZE
-reports exactly 1/2 of the bytes of a wide coalesced streaming read").  bench.py reads the newest
-profiles/*_traffic.json for its roofline.traffic field.
+reports exactly 1/2 of the bytes of a wide coalesced streaming read").  The summary is stamped with a hash of the
+kernel sources (bench.csrc_hash); bench.py reports roofline.traffic only from a summary whose stamp matches the
+sources it runs, and `traffic: null, traffic_stale: true` otherwise.  Run it right after tools/profile_bench.sh,
+before editing smrt_amd/csrc/.
 """
 import collections
 import csv
@@ -46,7 +48,9 @@ def main():
     stats = {short(r["Name"]): r for r in csv.DictReader(open(os.path.join(src, "trace", "bench_kernel_stats.csv")))}
     fetch, nf = per_kernel_counter(os.path.join(src, "fetch", "bench_counter_collection.csv"), "FETCH_SIZE")
     write, nw = per_kernel_counter(os.path.join(src, "write", "bench_counter_collection.csv"), "WRITE_SIZE")
-    out = {"command": "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-balance",
+    sys.path.insert(0, ROOT)
+    from bench import csrc_hash
+    out = {"csrc_hash": csrc_hash(), "command": "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-balance",
            "units": "bytes per launch; FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled (gfx950 correction)", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if k not in stats or not (k.startswith("fused") or k.startswith("gemm") or k.startswith("dw_") or
