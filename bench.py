@@ -139,7 +139,7 @@ def tabular_c2(n=1000000, n_minor=N_MINORITY, seed=42):
 
 def balance_c3_wallclock(dist, dev):
     """Config C3 end to end: 50 000 majority + 8 minority classes x 5 000 rows, 784-d, the reference's
-    own network (784-450-(10,10)) at API defaults, balance_ratio 0.5 -> 8 x 20 000 synthetic rows, fp64 250 000 x 784 out.
+    own network (784-450-(10,10)), API defaults but learning_rate 0.005, balance_ratio 0.5 -> 8 x 20 000 synthetic rows, fp64 250 000 x 784 out.
     Every rank makes the identical call; the eight per-class fit -> generate jobs go to the ranks longest first, there
     is no collective on the data path, finished blocks are broadcast once.  Wall-clock = max over ranks, median of 2."""
     import torch
@@ -148,12 +148,14 @@ def balance_c3_wallclock(dist, dev):
     Xs, ys = [], []
     for label, n in [(0, 50000)] + [(k, 5000) for k in range(1, 9)]:
         proto, mask = rs.uniform(size=784), rs.uniform(size=784) < 0.2
-        Xs.append((np.clip(proto + 0.15 * rs.normal(size=(n, 784)), 0, 1) * mask).astype(np.float32))
+        Xs.append((0.9 * np.clip(proto + 0.15 * rs.normal(size=(n, 784)), 0, 1) * mask).astype(np.float32))
         ys.append(np.full(n, label))
     X, y = np.vstack(Xs), np.concatenate(ys)
     p = rs.permutation(len(y))
     X, y = X[p], y[p]
-    kw = dict(n_hidden=450, n_latent_factors=10, balance_ratio=0.5, random_state=42)
+    # learning_rate 0.005, every other parameter the API default: at the default 0.05 the reference algorithm itself runs
+    # into p == 1.0f and an inf / NaN cost on this data after three epochs (tests/test_gpu_configs.py)
+    kw = dict(n_hidden=450, n_latent_factors=10, balance_ratio=0.5, random_state=42, learning_rate=0.005)
     smrt_balance(X[:9000], y[:9000], n_epochs=1, **kw)                       # warm-up (library, RCCL)
     times = []
     for _ in range(2):
@@ -170,6 +172,7 @@ def balance_c3_wallclock(dist, dev):
         times.append(dt)
     counts = np.unique(yb, return_counts=True)[1]
     assert Xb.shape == (250000, 784) and counts.tolist() == [50000] + [25000] * 8, (Xb.shape, counts)
+    assert np.isfinite(Xb).all()
     return {"workload": "C3: smrt_balance, 8 minority classes x 5000 x 784 + 50000 majority -> 250000 x 784 fp64",
             "wall_s": float(np.median(times)), "wall_s_all": times, "class_jobs": 8,
             "parallelism": "per-class jobs over %d rank(s)" % (dist.get_world_size() if dist is not None else 1)}

@@ -41,10 +41,10 @@ def _pair(D, hidden, Z, act, opt, max_batch, rs, lr=0.001, seed=3):
     return o, h
 
 
-def _mnist_shaped(rs, n, d=784):
-    """per-class prototype + noise, ~80 % exact zeros."""
+def _mnist_shaped(rs, n, d=784, ink=0.9):
+    """per-class prototype + noise, ~80 % exact zeros (brightest pixel `ink`)."""
     proto, mask = rs.uniform(size=d), rs.uniform(size=d) < 0.2
-    return (np.clip(proto + 0.15 * rs.normal(size=(n, d)), 0, 1) * mask).astype(np.float32)
+    return (ink * np.clip(proto + 0.15 * rs.normal(size=(n, d)), 0, 1) * mask).astype(np.float32)
 
 
 def _check_adam_step(o, h, p_before, c_h, g_h, c_o, gW, gb, what):
@@ -125,8 +125,11 @@ def test_c5_net_one_step_adam_and_generation_of_a_million_rows():
 
 def test_c3_full_size_balance():
     """Config C3 at full size through smrt_balance (one GPU here; the ranks only partition the same class jobs):
-    50 000 majority + 8 minority classes x 5 000 rows x 784, N1, API defaults, balance_ratio 0.5 -> 8 x 20 000 synthetic
-    rows.  Counts; the original rows bit-identical and first (shuffle=False); and EVERY class's synthetic block equal to
+    50 000 majority + 8 minority classes x 5 000 rows x 784, N1, balance_ratio 0.5 -> 8 x 20 000 synthetic rows; API
+    defaults except learning_rate = 0.005.  (At the default 0.05 the REFERENCE ALGORITHM leaves the finite numbers on
+    this data: 800 rms_prop steps of ~0.05 per weight drive a decoder pre-activation past 17, p == 1.0f, fp32's
+    1 - 1e-10 == 1.0f is no upper clip (_ae_utils.py:31) and the cost is inf from epoch 3-4 on -- in the
+    oracle and in the kernels alike.  Parity of trained states is only meaningful on finite numbers.)  Counts; the original rows bit-identical and first (shuffle=False); and EVERY class's synthetic block equal to
     the oracle's decode of the reference's numpy draws (one shared RandomState(42), normal((obs_req, Z)) per class in label
     order, smrt.py:229-230 / autoencoder.py:571) through that class's trained weights."""
     from smrt_amd.balance import smrt_balance
@@ -139,7 +142,7 @@ def test_c3_full_size_balance():
     p = rs.permutation(len(y))
     X, y = X[p], y[p]
     Xb, yb, enc = smrt_balance(X, y, n_hidden=450, n_latent_factors=10, balance_ratio=0.5, random_state=42,
-                               shuffle=False, return_estimators=True)
+                               learning_rate=0.005, shuffle=False, return_estimators=True)
     assert Xb.shape == (250000, 784) and Xb.dtype == np.float64
     assert np.unique(yb, return_counts=True)[1].tolist() == [50000] + [25000] * 8
     np.testing.assert_array_equal(Xb[:90000], X)
@@ -152,8 +155,11 @@ def test_c3_full_size_balance():
         z = stream.normal(size=(20000, 10))
         o = OracleVAE(784, [450], 10, seed=42)
         o.params = [(W, b) for W, b in unflatten_params(enc[k].sess.get_params(), 784, [450], 10)]
-        _close(Xb[row:row + 20000], o.decode(z), "class %d synthetic block" % k)
-        assert len(enc[k].epoch_costs_) == 20 and np.all(np.isfinite(enc[k].epoch_costs_))
+        block = Xb[row:row + 20000]
+        assert np.isfinite(block).all() and block.min() >= 0.0 and block.max() < 1.0
+        _close(block, o.decode(z), "class %d synthetic block" % k)
+        costs = np.asarray(enc[k].epoch_costs_)
+        assert len(costs) == 20 and np.all(np.isfinite(costs)) and costs[-1] < costs[0]
         row += 20000
     for e in enc.values():
         if e is not None:
@@ -193,46 +199,56 @@ def test_adam_wide_net_epochs():
     X = rs.uniform(0, 1, size=(700, D))
     costs, _ = h.train_epochs(X, 300, 3)
     o.fit(X, n_epochs=3, batch_size=300)
-    np.testing.assert_allclose(costs, np.asarray(o.epoch_costs_, np.float32), rtol=2e-4)
+    np.testing.assert_allclose(costs, np.asarray(o.epoch_costs_, np.float32), rtol=1e-4)
     slots = o.opt.state_arrays()
     _close(h.get_opt_state(0), _flat_slot(slots["m"]), "Adam m after 3 epochs", rtol=1e-3)
     _close(h.get_opt_state(1), _flat_slot(slots["v"]), "Adam v after 3 epochs", rtol=1e-3)
     h.close()
 
 
-def test_c1_trained_state_parity(tmp_path):
-    """Config C1's fit at the reference's own test settings (smrt/balance/tests/test_smrt.py:17-21: N1, lr 0.05, 50 epochs,
-    batch 256, rms_prop) on the 500-row minority class of the MNIST-shaped stand-in: 100 steps with the same initial
-    weights and the same Philox epsilon on both sides.  This is where the fast intrinsics of the BCE epilogue
-    (v_exp/v_rcp sigmoid, v_log, v_rcp) meet saturated outputs: ~80 % of the pixels are exact zeros, so the trained
-    decoder drives p towards 0 there.  Every epoch's last-batch cost, the final weights and generate(2222) are compared;
-    the measured deviations are written to gpurun_out/trained_parity.json."""
+def test_c1_trained_state_parity():
+    """Config C1's fit (smrt/balance/tests/test_smrt.py:17-21: N1, 50 epochs, batch 256, rms_prop) on the 500-row minority
+    class of the MNIST-shaped stand-in: 100 steps with the same initial weights and the same Philox epsilon on both
+    sides.  This is where the fast intrinsics of the BCE epilogue (v_exp / v_rcp sigmoid, v_log, v_rcp) meet saturated
+    outputs: ~80 % of the pixels are exact zeros and the trained decoder drives p to 1e-18 there.
+
+    Two learning rates.  At 0.005 the trajectory is well-conditioned (the oracle in fp32 and in fp64 end 1.2e-7 apart),
+    so everything is compared after all 50 epochs: every epoch's last-batch cost, the final weights, generate(2222).
+    At the reference test's own 0.05 the trajectory is chaotic -- the fp32 and fp64 ORACLES are 8e-5 apart in cost by epoch
+    20 and 0.11 apart in the weights by epoch 50 -- so only the first 10 epochs (oracle fp32 vs fp64: < 3e-7) can be held
+    to the bar.  The measured deviations are written to gpurun_out/trained_parity.json."""
     import json
     import os
     from smrt_amd.autoencode import VariationalAutoEncoder
     rs = np.random.RandomState(2)
     X = _mnist_shaped(rs, 500)
-    kw = dict(learning_rate=0.05, n_epochs=50, batch_size=256)
-    ae = VariationalAutoEncoder(n_hidden=450, n_latent_factors=10, random_state=42, **kw).fit(X)
-    o = OracleVAE(784, [450], 10, seed=42, learning_rate=0.05)
-    o.fit(X, n_epochs=50, batch_size=256)
-    costs_h, costs_o = np.asarray(ae.epoch_costs_, np.float64), np.asarray(o.epoch_costs_, np.float64)
-    p_h, p_o = ae.sess.get_params().astype(np.float64), flatten_params(o.params).astype(np.float64)
-    g_h = ae.generate(2222)
-    g_o = o.generate(np.random.RandomState(42), 2222)
-    dev = {"cost_rel_max": float(np.max(np.abs(costs_h - costs_o) / np.abs(costs_o))),
-           "cost_rel_first_epoch": float(abs(costs_h[0] - costs_o[0]) / abs(costs_o[0])),
-           "param_abs_max": float(np.max(np.abs(p_h - p_o))), "param_scale": float(np.max(np.abs(p_o))),
-           "generate_abs_max": float(np.max(np.abs(g_h - g_o))),
-           "generate_min": float(g_h.min()), "generate_max": float(g_h.max()),
-           "final_cost": float(costs_h[-1]), "first_cost": float(costs_h[0])}
+    dev = {}
+    for lr, n_cmp in ((0.005, 50), (0.05, 10)):
+        ae = VariationalAutoEncoder(n_hidden=450, n_latent_factors=10, random_state=42, learning_rate=lr, n_epochs=50,
+                                    batch_size=256).fit(X)
+        o = OracleVAE(784, [450], 10, seed=42, learning_rate=lr)
+        o.fit(X, n_epochs=n_cmp, batch_size=256)
+        costs_h, costs_o = np.asarray(ae.epoch_costs_, np.float64)[:n_cmp], np.asarray(o.epoch_costs_, np.float64)
+        d = {"epochs_compared": n_cmp, "cost_rel_max": float(np.max(np.abs(costs_h - costs_o) / np.abs(costs_o))),
+             "first_cost": float(costs_h[0]), "last_cost": float(costs_h[-1])}
+        assert np.all(np.isfinite(ae.epoch_costs_))
+        if n_cmp == 50:
+            p_h, p_o = ae.sess.get_params().astype(np.float64), flatten_params(o.params).astype(np.float64)
+            g_h, g_o = ae.generate(2222), o.generate(np.random.RandomState(42), 2222)
+            d.update({"param_abs_max": float(np.max(np.abs(p_h - p_o))), "param_scale": float(np.max(np.abs(p_o))),
+                      "generate_abs_max": float(np.max(np.abs(g_h - g_o))),
+                      "generate_rel_max_above_1e-3": float(np.max(np.abs(g_h - g_o)[g_o > 1e-3] / g_o[g_o > 1e-3])),
+                      "generate_min": float(g_h.min()), "generate_max": float(g_h.max())})
+        dev["lr_%g" % lr] = d
+        ae.clean_session()
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     json.dump(dev, open(os.path.join(out_dir, "trained_parity.json"), "w"), indent=1)
     print("trained-state deviations:", dev)
-    assert costs_h[-1] < 0.7 * costs_h[0]                      # it did train
-    assert dev["cost_rel_first_epoch"] < 1e-4                  # two steps in: the per-step bar
-    assert dev["cost_rel_max"] < 5e-4                          # 100 steps of fp32 summation-order drift, measured
-    assert dev["param_abs_max"] < 1e-3 * dev["param_scale"]
-    assert dev["generate_abs_max"] < 1e-3
-    ae.clean_session()
+    a, b = dev["lr_0.005"], dev["lr_0.05"]
+    assert a["last_cost"] < 0.5 * a["first_cost"]               # it did train
+    # north_star's bar is 1e-4; measured on MI355X (profiles/r02_trained_parity.json): costs 2.2e-7 / 1.3e-7, weights
+    # 8.2e-8 of a 0.14 scale, generate 4.2e-7 absolute and 3.9e-6 relative -- asserted with a factor of ~10 in hand
+    assert a["cost_rel_max"] < 5e-6 and b["cost_rel_max"] < 5e-6
+    assert a["param_abs_max"] < 1e-5 * a["param_scale"]
+    assert a["generate_abs_max"] < 1e-5 and a["generate_rel_max_above_1e-3"] < 1e-4
