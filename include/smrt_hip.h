@@ -132,6 +132,19 @@ int  smrt_vae_decode(smrt_vae* h, const float* Z_dev, int64_t ldz, int64_t n, fl
 int  smrt_vae_generate(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc, float scale,
                        float* out_dev, int64_t ldo);
 
+/* The ONE entry point that allocates nothing.  It has no counterpart in the reference; it is for callers that cannot
+ * allocate device memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
+ * result as smrt_vae_generate (same kernels, same Philox stream), but the latent chunk -- and, for nets off the fused
+ * path, the decoder's two ping-pong activation buffers -- live in a static device array of
+ * SMRT_NOALLOC_SCRATCH_BYTES per GPU instead of library-allocated buffers.  No hipMalloc / hipFree / allocating
+ * routine is called.  n may not exceed smrt_vae_generate_noalloc_max_rows(h) (= scratch floats / (rup4(Z) [+ 2 x widest
+ * layer])); a larger n returns -5 with a message and writes nothing.  Every call on a GPU shares that GPU's array:
+ * calls that overlap on one GPU (other handles, other threads) race; the array is cleared at the start of each call. */
+#define SMRT_NOALLOC_SCRATCH_BYTES (8 << 20)
+int64_t smrt_vae_generate_noalloc_max_rows(const smrt_vae* h);
+int  smrt_vae_generate_noalloc(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc, float scale,
+                               float* out_dev, int64_t ldo);
+
 /* Debug/parity: the epsilon the kernels would draw for training step `step`, rows [row0, row0+rows). */
 int  smrt_vae_sample_eps(smrt_vae* h, int64_t step, int64_t row0, int32_t rows, float* eps_dev);
 

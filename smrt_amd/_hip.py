@@ -26,7 +26,7 @@ EXPORTS = [
     "smrt_vae_set_dropout_masks", "smrt_vae_train_step", "smrt_vae_train_epochs", "smrt_vae_dp_count",
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
-    "smrt_vae_generate", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
+    "smrt_vae_generate", "smrt_vae_generate_noalloc", "smrt_vae_generate_noalloc_max_rows", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
     "smrt_assemble_rows", "smrt_assemble_rows_part", "smrt_assemble_rows_f64", "smrt_all_finite", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_mfma_peak_16x16x4", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
     "smrt_last_error", "smrt_version",
 ]
@@ -96,6 +96,8 @@ def load():
     lib.smrt_vae_encode.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.smrt_vae_decode.argtypes = [vp, vp, i64, i64, vp, i64]
     lib.smrt_vae_generate.argtypes = [vp, i64, C.c_uint64, C.c_float, C.c_float, vp, i64]
+    lib.smrt_vae_generate_noalloc.argtypes = [vp, i64, C.c_uint64, C.c_float, C.c_float, vp, i64]
+    lib.smrt_vae_generate_noalloc_max_rows.argtypes = [vp]; lib.smrt_vae_generate_noalloc_max_rows.restype = i64
     lib.smrt_vae_sample_eps.argtypes = [vp, i64, i64, i32, vp]
     lib.smrt_vae_profile_epochs.argtypes = [vp, vp, i64, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(i64)]
     lib.smrt_assemble_rows.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32]
@@ -550,6 +552,16 @@ class VaeHandle(object):
                                                out.data_ptr(), out.shape[1]), "smrt_vae_generate")
         out = out[:, :self.n_features]
         return out.cpu().numpy() if to_host else out
+
+    @property
+    def generate_noalloc_max_rows(self):
+        return int(self._lib.smrt_vae_generate_noalloc_max_rows(self._live()))
+
+    def generate_noalloc(self, out, n, philox_offset=0, loc=0.0, scale=1.0):
+        """``generate`` into the caller's fp32 device tensor ``out`` [>= n, ld >= n_features] through the entry point
+        that allocates nothing (static per-GPU scratch, ``generate_noalloc_max_rows`` rows at most)."""
+        _check(self._lib.smrt_vae_generate_noalloc(self._live(), int(n), int(philox_offset), float(loc), float(scale),
+                                                   out.data_ptr(), out.stride(0)), "smrt_vae_generate_noalloc")
 
     def sample_eps(self, step, row0, rows):
         torch = _torch()

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1061,6 +1062,19 @@ int smrt_vae_profile_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_
 static const long INFER_CHUNK = 32768;
 static const long INFER_CHUNK_FUSED = 1L << 20;      // rows of z drawn per launch on the fused path
 
+// Whether infer_fused would take layers [l0, l1] (the same tests it applies, without enqueuing anything).
+static bool infer_fused_fits(const smrt_vae* h, int l0, int l1) {
+    if (!h->fused || !h->Wimg) return false;
+    const char* e = std::getenv("SMRT_HIP_FUSED_INFER");
+    if (e && std::atoi(e) == 0) return false;
+    int maxw = rup16(h->flay[l0].fi);
+    for (int l = l0; l <= l1; ++l) maxw = std::max(maxw, rup16(h->flay[l].fo));
+    if (maxw / 16 > 8) return false;
+    const int start = h->flay[l0].lds_w, end = h->flay[l1].lds_b + 4 * rup16(h->flay[l1].fo);
+    const int ts = std::max(rup16(h->flay[l0].fi), rup16(h->flay[l1].fo)) + 4;
+    return (end - start) * 4 + 8 * 16 * ts * 4 <= 160 * 1024;
+}
+
 // Layers [l0, l1] of a net on the fused path in ONE persistent launch (fused_infer_kernel).  Returns 1 when the launch was
 // enqueued, 0 when this net / call does not qualify (the caller then runs the per-layer GEMM chain), < 0 on error.
 static int infer_fused(smrt_vae* h, int l0, int l1, const float* in, long ldin, long n,
@@ -1140,14 +1154,16 @@ int smrt_vae_encode(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n, flo
     return 0;
 }
 
-static int decode_chunk(smrt_vae* h, const float* Zin, long ldz, int rows, float* out, long ldo) {
+static int decode_chunk(smrt_vae* h, const float* Zin, long ldz, int rows, float* out, long ldo,
+                        float* ib0 = nullptr, float* ib1 = nullptr) {
+    float* ib[2] = {ib0 ? ib0 : h->ibuf[0], ib1 ? ib1 : h->ibuf[1]};
     const float* in = Zin; long ldin = ldz;
     for (int l = h->dec0; l < h->NL; ++l) {
         const LayerI& y = h->lay[l];
         GemmArgs a{};
         a.A = in; a.lda = ldin; a.B = h->W + y.off; a.ldb = y.ld; a.bias = h->W + y.off + (long)y.fi * y.ld;
         a.M = rows; a.N = y.fo; a.K = y.fi; a.act = y.act; a.Z = h->Z;
-        if (l < h->NL - 1) { a.C = h->ibuf[l & 1]; a.ldc = y.ld; }
+        if (l < h->NL - 1) { a.C = ib[l & 1]; a.ldc = y.ld; }
         else               { a.C = out; a.ldc = ldo; }
         launch_gemm(h->stream, GEMM_NN, EPI_BIAS_ACT, a);
         in = a.C; ldin = y.ld;
@@ -1204,6 +1220,85 @@ int smrt_vae_generate(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc,
                 const int cr = (int)std::min<long>(INFER_CHUNK, rows - c0);
                 TRY(decode_chunk(h, h->izb + c0 * ldz, ldz, cr, out_dev + (r0 + c0) * ldo, ldo));
             }
+        }
+    }
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- the entry point that allocates nothing (include/smrt_hip.h: smrt_vae_generate_noalloc) ----------------------
+// smrt_vae_generate draws its latent chunk into a library-allocated buffer (ensure_infer -> hipMalloc) and, for nets off
+// the fused path, ping-pongs the decoder's activations through two more.  Here the same kernels take those buffers from
+// ONE file-scope device array: each GPU the library runs on holds its own copy (SMRT_NOALLOC_SCRATCH_BYTES) at its own
+// address until the process ends.  `scratch` below is only a host-side stand-in for that array: host code never passes
+// it to a kernel or a memset; it asks the runtime for the array's address on the current device, once per device, and
+// uses that pointer.
+#define SMRT_NOALLOC_SCRATCH_FLOATS (SMRT_NOALLOC_SCRATCH_BYTES / 4)
+static __device__ __align__(256) __attribute__((used)) float scratch[SMRT_NOALLOC_SCRATCH_FLOATS];
+constexpr int SMRT_MAX_DEVICES = 64;
+static float* g_scratch_ptr[SMRT_MAX_DEVICES] = {nullptr};
+static std::mutex g_scratch_mu;
+
+// Address of this device's copy of `scratch` (resolved on first use, with `device` current).
+static int scratch_on(int device, float** out) {
+    if (device < 0 || device >= SMRT_MAX_DEVICES) return fail(-1, "smrt_vae_generate_noalloc: device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        float* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            return fail(-2, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+
+int64_t smrt_vae_generate_noalloc_max_rows(const smrt_vae* h) {
+    if (!h || h->ae) return -1;
+    const long ldz = rup4(h->Z);
+    const bool fused_ok = h->fused && h->Wimg && h->fplan.img_total > 0 && infer_fused_fits(h, h->dec0, h->NL - 1);
+    const long per_row = fused_ok ? ldz : ldz + 2L * h->maxld;      // z (+ two activation rows off the fused path)
+    return (long)SMRT_NOALLOC_SCRATCH_FLOATS / per_row;
+}
+
+int smrt_vae_generate_noalloc(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc, float scale,
+                              float* out_dev, int64_t ldo) {
+    if (!h || !out_dev) return fail(-1, "smrt_vae_generate_noalloc: null argument");
+    if (n < 0) return fail(-1, "smrt_vae_generate_noalloc: n must be >= 0");
+    if (h->ae) return fail(-1, "smrt_vae_generate_noalloc: a plain auto-encoder has no generative prior");
+    if (ldo < h->D) return fail(-1, "smrt_vae_generate_noalloc: ldo must be >= n_features");
+    const int64_t cap = smrt_vae_generate_noalloc_max_rows(h);
+    if (n > cap)
+        return fail(-5, "smrt_vae_generate_noalloc: " + std::to_string(n) + " rows exceed the " + std::to_string(cap) +
+                        " rows this net can generate from the " + std::to_string(SMRT_NOALLOC_SCRATCH_BYTES >> 20) +
+                        " MiB static scratch; use smrt_vae_generate or split the call");
+    if (n == 0) return 0;
+    HIPC(hipSetDevice(h->device));
+    float* sp = nullptr;
+    TRY(scratch_on(h->device, &sp));
+    const long ldz = rup4(h->Z);
+    const bool fused_ok = h->fused && h->Wimg && infer_fused_fits(h, h->dec0, h->NL - 1);
+    // carve: [z : n x ldz] [activations A : n x maxld] [activations B : n x maxld], each piece 256-byte aligned by
+    // construction (ldz and maxld are multiples of 4 floats; round the piece sizes up to 64 floats)
+    const size_t zf = ((size_t)n * ldz + 63) & ~size_t(63);
+    const size_t af = fused_ok ? 0 : (((size_t)n * h->maxld + 63) & ~size_t(63));
+    if (zf + 2 * af > (size_t)SMRT_NOALLOC_SCRATCH_FLOATS) return fail(-5, "smrt_vae_generate_noalloc: internal: carve exceeds the scratch");
+    float* zbuf = sp;
+    float* ib0 = af ? sp + zf : nullptr;
+    float* ib1 = af ? sp + zf + af : nullptr;
+    // the array keeps the last call's contents: pad columns of the pieces must read as zero
+    HIPC(hipMemsetAsync(sp, 0, (zf + 2 * af) * sizeof(float), h->stream));
+    launch_sample_normal(h->stream, zbuf, ldz, n, h->Z, h->cfg.seed, 3u, 0u, philox_offset, loc, scale);
+    int f = 0;
+    if (fused_ok) f = infer_fused(h, h->dec0, h->NL - 1, zbuf, ldz, n, out_dev, ldo, h->D, nullptr, 0);
+    if (f < 0) return f;
+    if (!f) {
+        if (!af) return fail(-4, "smrt_vae_generate_noalloc: the fused launch was refused and no activation scratch was carved");
+        for (long c0 = 0; c0 < n; c0 += INFER_CHUNK) {
+            const int cr = (int)std::min<long>(INFER_CHUNK, n - c0);
+            TRY(decode_chunk(h, zbuf + c0 * ldz, ldz, cr, out_dev + c0 * ldo, ldo, ib0, ib1));
         }
     }
     HIPC(hipGetLastError());
