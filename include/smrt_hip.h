@@ -155,7 +155,8 @@ int  smrt_vae_last_epoch_launches(const smrt_vae* h);
  * every kernel launch on the handle's stream; returns total ms and launch count per kernel kind
  * (SMRT_PK_*).  It trains exactly like smrt_vae_train_epochs (weights advance). */
 enum { SMRT_PK_DROPOUT = 0, SMRT_PK_FWD, SMRT_PK_FWD_BCE, SMRT_PK_REPARAM, SMRT_PK_BWD, SMRT_PK_BWD_LATENT,
-       SMRT_PK_DW, SMRT_PK_OPT, SMRT_PK_FINAL, SMRT_PK_REDUCE, SMRT_PK_FUSED, SMRT_PK_FUSED_DW_OPT, SMRT_PK_COUNT };
+       SMRT_PK_DW, SMRT_PK_OPT, SMRT_PK_FINAL, SMRT_PK_REDUCE, SMRT_PK_FUSED, SMRT_PK_FUSED_DW_OPT, SMRT_PK_PERSIST,
+       SMRT_PK_COUNT };
 int  smrt_vae_profile_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n_rows, int32_t batch_size,
                              int32_t n_epochs, double* ms_by_kind, int64_t* launches_by_kind);
 

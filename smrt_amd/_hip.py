@@ -446,7 +446,7 @@ class VaeHandle(object):
         return costs[:done.value].copy(), ms[:done.value].copy()
 
     PROFILE_KINDS = ("dropout", "fwd_gemm", "fwd_gemm_bce", "reparam", "bwd_gemm", "bwd_gemm_latent", "dw_gemm",
-                     "optimizer", "finalize", "reduce_slabs", "fused_fwd_bwd", "fused_dw_opt")
+                     "optimizer", "finalize", "reduce_slabs", "fused_fwd_bwd", "fused_dw_opt", "persist_train")
 
     def profile_epochs(self, X, batch_size, n_epochs):
         """Eager epochs with a hipEvent pair around every kernel: {kind: (total ms, launches)}."""

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -92,6 +93,10 @@ struct smrt_vae {
     float* Wimg = nullptr;           // LDS-image twin of the parameters (fplan.img_total floats)
     bool img_valid = false;          // Wimg matches W (kept current by the fused optimizer epilogue)
     DwTile* tile_tab = nullptr;      // per-tile records of the fused dW + optimizer kernel
+    // persistent whole-epoch kernel (persist_train.hip)
+    bool persist_ok = false;         // the net qualifies (fits in LDS, no dropout, VAE)
+    unsigned* pcnt = nullptr;        // counters + error word (64 words)
+    int persist_wgs_held = 0;        // workgroups reserved in the process-wide budget while a call runs
 
     // per-kernel profiling (eager launches bracketed by events)
     bool prof = false;
@@ -101,7 +106,7 @@ struct smrt_vae {
 };
 
 enum ProfKind : int { PK_DROPOUT = 0, PK_FWD, PK_FWD_BCE, PK_REPARAM, PK_BWD, PK_BWD_LATENT, PK_DW, PK_OPT,
-                      PK_FINAL, PK_REDUCE, PK_FUSED, PK_FUSED_DW_OPT, PK_COUNT };
+                      PK_FINAL, PK_REDUCE, PK_FUSED, PK_FUSED_DW_OPT, PK_PERSIST, PK_COUNT };
 
 static void drop_graph(smrt_vae* h) {
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
@@ -239,6 +244,21 @@ static void plan_fused(smrt_vae* h) {
     const int bytes = off * (int)sizeof(float);
     h->fused = want && bytes <= 150 * 1024 && !h->ae;
     if (h->fused && bytes > 48 * 1024 && fused_set_max_lds(bytes) != 0) { (void)hipGetLastError(); h->fused = false; }
+    const char* pe = std::getenv("SMRT_HIP_PERSIST");
+    h->persist_ok = h->fused && (pe ? std::atoi(pe) != 0 : true) && h->cfg.dropout_keep >= 1.0f;
+    if (h->persist_ok && bytes > 48 * 1024 && persist_set_max_lds(bytes) != 0) { (void)hipGetLastError(); h->persist_ok = false; }
+}
+
+// Workgroups of the persistent kernel for a mini-batch size; 0: this schedule does not take the persistent path.
+// One compute workgroup per 16 rows (+ one owner wave per weight-gradient tile, persist_owner_workgroups).  Co-residency of the whole grid is what its counters rely on: all persistent launches of
+// the process together are kept to PERSIST_WG_BUDGET of the 256 CUs (one workgroup per CU: LDS), the rest take the
+// two-kernel step.
+constexpr int PERSIST_ROWS_MAX = 512;
+constexpr int PERSIST_WG_BUDGET = 160;
+static std::atomic<int> g_persist_wgs{0};
+static int persist_grid(const smrt_vae* h, long batch_rows) {
+    if (!h->persist_ok || batch_rows > PERSIST_ROWS_MAX || batch_rows < 1) return 0;
+    return (int)((batch_rows + 15) / 16);
 }
 
 // Zero-fills go on the handle's stream and are waited for there: a device-wide synchronise is refused by the runtime
@@ -384,6 +404,102 @@ static int check_mat(const void* p, int64_t ld, int cols, const char* what) {
     return 0;
 }
 
+// Stage table of the LDS-resident kernels: forward through every layer, then backward through the activations.
+static int build_stages(const smrt_vae* h, const FusedArgs& f, FusedStage* stages) {
+    const int L = h->L, NL = h->NL;
+    int ns = 0;
+    for (int l = 0; l < NL; ++l) {
+        const FusedLayer& q = h->flay[l];
+        FusedStage& t = stages[ns++];
+        t = FusedStage{};
+        t.in_off = (l == 0) ? f.lds_x : (l == L + 1 ? f.lds_z : h->flay[l - 1].lds_out);
+        t.sin = (l == 0) ? f.s_x : (l == L + 1 ? f.s_z : h->flay[l - 1].s_out);
+        t.K16 = rup16(q.fi); t.w_off = q.lds_w; t.nn = q.nn; t.N = q.fo; t.act = q.act; t.b_off = q.lds_b;
+        t.trans = 0; t.NF = rup16(q.fo);
+        if (l < NL - 1) {
+            t.kind = (l == L) ? FK_FWD_HEADS : FK_FWD_ACT;
+            t.out_off = q.lds_out; t.s_out = q.s_out; t.gout = h->outT[l];
+        } else {
+            t.kind = FK_FWD_BCE; t.out_off = f.lds_d0; t.s_out = f.s_d; t.aux_off = f.lds_x; t.s_aux = f.s_x;
+            t.gout = h->dpreT[l];
+        }
+    }
+    int cur = f.lds_d0, nxt = f.lds_d1;
+    for (int l = NL - 1; l >= 1; --l) {
+        const FusedLayer& q = h->flay[l];
+        const FusedLayer& pq = h->flay[l - 1];
+        FusedStage& t = stages[ns++];
+        t = FusedStage{};
+        t.in_off = cur; t.sin = f.s_d; t.K16 = rup16(q.fo); t.w_off = q.lds_w; t.nn = q.nn; t.trans = 1;
+        t.N = q.fi; t.act = pq.act; t.out_off = nxt; t.s_out = f.s_d;
+        t.aux_off = pq.lds_out; t.s_aux = pq.s_out; t.NF = rup16(pq.fo); t.gout = h->dpreT[l - 1];
+        t.kind = (l == L + 1) ? FK_BWD_LATENT : FK_BWD_ACT;
+        std::swap(cur, nxt);
+    }
+    return ns;
+}
+
+// One whole epoch (every contiguous mini-batch, ragged tail last) in ONE persistent launch + the cost of the last batch.
+// Returns the number of launches enqueued.
+static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_rows, int batch, int G, float* cost_slot) {
+    hipStream_t s = h->stream;
+    const FusedArgs& f = h->fplan;
+    PersistArgs a{};
+    a.n_stages = build_stages(h, f, a.stages);
+    const int n_owner = persist_owner_workgroups(h->tiles16);
+    a.G = G;
+    a.NL = h->NL; a.L = h->L; a.Z = h->Z; a.D = h->D;
+    a.X = X; a.ldx = ldx; a.n_rows = n_rows; a.batch = batch; a.n_steps = (int)((n_rows + batch - 1) / batch);
+    a.Wimg = h->Wimg; a.img_total = f.img_total; a.W = h->W; a.s0 = h->s0; a.s1 = h->s1;
+    a.tiles = h->tile_tab; a.total_tiles = h->tiles16; a.XT = h->XT; a.Zb_g = h->ZT; a.cap_blocks = h->cap_rows / 16;
+    a.cnt = h->pcnt;
+    a.lds_x = f.lds_x; a.s_x = f.s_x; a.lds_z = f.lds_z; a.lds_e = f.lds_e; a.s_z = f.s_z; a.lds_total = f.lds_total;
+    a.seed = h->cfg.seed; a.st = h->st; a.lo = h->cfg.bce_lo; a.hi = h->cfg.bce_hi;
+    a.bce_p = h->bce_p; a.kl_p = h->kl_p; a.l2_p = h->l2_p;
+    a.opt = h->cfg.optimizer; a.clip = h->cfg.clip; a.has_l2 = h->has_l2 ? 1 : 0;
+    a.lr = h->cfg.learning_rate; a.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
+    a.gmin = h->cfg.gclip_min; a.gmax = h->cfg.gclip_max;
+    // counters and the error word start at zero for every launch (stream-ordered, no host wait)
+    if (hipMemsetAsync(h->pcnt, 0, 64 * sizeof(unsigned), s) != hipSuccess) return -1;
+#ifdef SMRT_STAMPS
+    static unsigned long long* pdbg = nullptr;
+    if (!pdbg) { (void)hipMalloc((void**)&pdbg, 64 * 8); (void)hipMemset(pdbg, 0, 64 * 8); }
+    a.dbg = pdbg;
+#endif
+    { ProfScope ps(h, PK_PERSIST); launch_persist_train(s, a, G + n_owner); }
+#ifdef SMRT_STAMPS
+    {
+        (void)hipStreamSynchronize(s);
+        unsigned long long hb[64];
+        (void)hipMemcpy(hb, pdbg, 64 * 8, hipMemcpyDeviceToHost);
+        static int once = 0;
+        if (once++ == 2) {
+            const char* nm[64] = {nullptr};
+            nm[1] = "weights published (poll)"; nm[2] = "image -> LDS"; nm[3] = "x tile, barrier";
+            nm[40] = "stages done"; nm[41] = "stores drained + barrier";
+            unsigned long long prev = hb[0];
+            for (int i = 1; i < 42; ++i) {
+                if (!hb[i]) continue;
+                char buf[64];
+                snprintf(buf, sizeof buf, "stage %d + barrier", i - 4);
+                fprintf(stderr, "persist stamp %2d %-40s +%.2f us\n", i, nm[i] ? nm[i] : buf, (double)(hb[i] - prev) * 0.01);
+                prev = hb[i];
+            }
+            fprintf(stderr, "owner: wait for rows %+.2f us after compute's signal | loads + MFMA %.2f | optimizer, stores, drain %.2f\n",
+                    ((double)hb[46] - (double)hb[41]) * 0.01, (double)(hb[47] - hb[46]) * 0.01, (double)(hb[48] - hb[47]) * 0.01);
+            fprintf(stderr, "persist step (compute workgroup 0, start -> signal) %.2f us\n", (double)(hb[41] - hb[0]) * 0.01);
+        }
+    }
+#endif
+    const long rows_last = n_rows - (long)(a.n_steps - 1) * batch;
+    FinalizeArgs fa{};
+    fa.bce = h->bce_p; fa.n_bce = (int)((rows_last + 15) / 16); fa.kl = h->kl_p; fa.n_kl = fa.n_bce;
+    fa.l2p = h->l2_p; fa.n_l2 = n_owner; fa.inv_batch = 1.0f / (float)rows_last; fa.l2 = a.l2;
+    fa.cost_out = cost_slot; fa.st = h->st; fa.advance = 0;
+    { ProfScope ps(h, PK_FINAL); launch_finalize(s, fa); }
+    return 2;
+}
+
 // ------------------------------------------------------------------ one training step, enqueued async
 struct StepOut { float* cost_slot; float* grad_out; float* dp_out; };
 
@@ -423,39 +539,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             h->img_valid = true;
         }
         FusedArgs f = h->fplan;
-        {
-            // stage table: forward through every layer, then backward through the activations
-            int ns = 0;
-            for (int l = 0; l < NL; ++l) {
-                const FusedLayer& q = h->flay[l];
-                FusedStage& t = f.stages[ns++];
-                t = FusedStage{};
-                t.in_off = (l == 0) ? f.lds_x : (l == L + 1 ? f.lds_z : h->flay[l - 1].lds_out);
-                t.sin = (l == 0) ? f.s_x : (l == L + 1 ? f.s_z : h->flay[l - 1].s_out);
-                t.K16 = rup16(q.fi); t.w_off = q.lds_w; t.nn = q.nn; t.N = q.fo; t.act = q.act; t.b_off = q.lds_b;
-                t.trans = 0; t.NF = rup16(q.fo);
-                if (l < NL - 1) {
-                    t.kind = (l == L) ? FK_FWD_HEADS : FK_FWD_ACT;
-                    t.out_off = q.lds_out; t.s_out = q.s_out; t.gout = h->outT[l];
-                } else {
-                    t.kind = FK_FWD_BCE; t.out_off = f.lds_d0; t.s_out = f.s_d; t.aux_off = f.lds_x; t.s_aux = f.s_x;
-                    t.gout = h->dpreT[l];
-                }
-            }
-            int cur = f.lds_d0, nxt = f.lds_d1;
-            for (int l = NL - 1; l >= 1; --l) {
-                const FusedLayer& q = h->flay[l];
-                const FusedLayer& pq = h->flay[l - 1];
-                FusedStage& t = f.stages[ns++];
-                t = FusedStage{};
-                t.in_off = cur; t.sin = f.s_d; t.K16 = rup16(q.fo); t.w_off = q.lds_w; t.nn = q.nn; t.trans = 1;
-                t.N = q.fi; t.act = pq.act; t.out_off = nxt; t.s_out = f.s_d;
-                t.aux_off = pq.lds_out; t.s_aux = pq.s_out; t.NF = rup16(pq.fo); t.gout = h->dpreT[l - 1];
-                t.kind = (l == L + 1) ? FK_BWD_LATENT : FK_BWD_ACT;
-                std::swap(cur, nxt);
-            }
-            f.n_stages = ns;
-        }
+        f.n_stages = build_stages(h, f, f.stages);
         f.X = X; f.ldx = ldx; f.rows = rows; f.eps_in = eps_in; f.Wimg = h->Wimg; f.Zb_g = h->ZT;
         f.XT = h->XT;
         f.seed = h->cfg.seed; f.st = h->st; f.row0_global = row0_global;
@@ -680,8 +764,9 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
             carve(a, &h->Wimg, h->fused ? (size_t)h->fplan.img_total + 16 : 0);
             carve(a, &h->st, (size_t)1);
             carve(a, &h->ticket, (size_t)4);
+            carve(a, &h->pcnt, (size_t)64);
             carve(a, &h->cost_dev, (size_t)4);
-            carve(a, &h->l2_p, (size_t)std::max(h->n_l2, dw_opt_blocks(h->tiles16)));
+            carve(a, &h->l2_p, (size_t)std::max(h->n_l2, dw_opt_blocks(h->tiles16)));      // (>= persist_owner_workgroups)
             carve(a, &h->stage_tab, h->fused ? (size_t)h->P_int / 4 : 0);
             carve(a, &h->gtmp, (size_t)h->P_int + 4);
             carve(a, &h->Wd, h->has_drop ? (size_t)h->P_int : 0);
@@ -868,11 +953,32 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     if (epochs_done) *epochs_done = 0;
     if (n_epochs == 0) return 0;
     ensure_image(h);
+    // The persistent whole-epoch kernel when the net and the schedule qualify and its workgroups fit the process-wide
+    // budget of co-resident persistent workgroups (released when this call returns, whichever way).
+    int PG = persist_grid(h, bmax);
+    const int PW = PG ? PG + persist_owner_workgroups(h->tiles16) : 0;          // workgroups of the launch
+    if (PG) {
+        const int prev = g_persist_wgs.fetch_add(PW);
+        if (prev + PW > PERSIST_WG_BUDGET) { g_persist_wgs.fetch_sub(PW); PG = 0; }
+    }
+    struct Release { int n; ~Release() { if (n) g_persist_wgs.fetch_sub(n); } } release{PG ? PW : 0};
+    auto persist_failed = [&]() -> bool {
+        if (!PG) return false;
+        unsigned e = 0;
+        if (hipMemcpy(&e, h->pcnt + 32, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return true;
+        return e != 0;
+    };
 
     // Enqueue one epoch (every contiguous batch, ragged tail last: sklearn gen_batches, base.py:198-199).
     // The cost of the LAST batch lands in `slot` (base.py:222); other steps write a scratch slot.
     auto enqueue_epoch = [&](float* slot) -> int {
         int launches = 0;
+        if (PG) {
+            launches = enqueue_persist_epoch(h, X_dev, ldx, n_rows, batch_size, PG, slot);
+            if (launches < 0) return fail(-2, "persistent epoch: counter reset failed");
+            h->last_epoch_launches = launches;
+            return 0;
+        }
         for (long b = 0; b < nb; ++b) {
             const long r0 = b * batch_size;
             const int rows = (int)std::min<long>(batch_size, n_rows - r0);
@@ -887,7 +993,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     // The epoch graph replays the identical epoch: every step-dependent scalar (Philox step, Adam powers)
     // lives in device memory, so only the cost slot differs -> the graph writes slot 0 and a copy node moves it.
     bool graphed = false;
-    if (h->use_graph && !h->prof && n_epochs > 1 && h->stream == h->own_stream) {
+    if (h->use_graph && !PG && !h->prof && n_epochs > 1 && h->stream == h->own_stream) {
         const bool hit = h->gexec && h->g_X == X_dev && h->g_ldx == ldx && h->g_n == n_rows && h->g_batch == batch_size;
         if (hit) graphed = true;
         else {
@@ -930,6 +1036,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
         if (rc) return rc;
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e));
+        if (persist_failed()) return fail(-6, "smrt_vae_train_epochs: the persistent training kernel gave up waiting for a peer workgroup (2 s); the handle's parameters are undefined");
         done = n_epochs;
     } else {
         for (int ep = 0; ep < n_epochs; ++ep) {
@@ -937,6 +1044,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
             if (rc) return rc;
             hipError_t e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e));
+            if (persist_failed()) return fail(-6, "smrt_vae_train_epochs: the persistent training kernel gave up waiting for a peer workgroup (2 s); the handle's parameters are undefined");
             done = ep + 1;
             const float c = h->cost_pin[ep];
             if (!have_last) { last_cost = c; have_last = true; }

@@ -23,84 +23,9 @@
 // Inside a 16-wide k-block the k order is permuted identically for both operands (lane group q takes
 // k = 16 kb + 4 q + s at step s) so an LDS A fragment is one ds_read_b128.  Four k-blocks feed four
 // independent accumulator chains (40-cycle dependent latency at a 32-cycle issue).
-#include "vae_kernels.hpp"
-#include "device_utils.hpp"
+#include "fused_stage.hpp"
 
 namespace smrt {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-// The stage records carry their output block as two 32-bit halves; a pointer rebuilt from integers is a GENERIC pointer
-// to the compiler, and stores through it are flat_store: they count on lgkmcnt as well (every later LDS wait becomes
-// lgkmcnt(0)) and issue through both address paths.  These types keep the stores global_store.
-typedef __attribute__((address_space(1))) float gfloat;
-typedef __attribute__((address_space(1))) f32x4 gf32x4;
-
-constexpr int FTM = 16;                 // rows per workgroup
-constexpr int FTHREADS = 512;          // 8 waves: two per SIMD, so one wave's epilogue/LDS latency hides under the other's MFMAs
-constexpr int FWAVES = FTHREADS / 64;
-constexpr int BTHREADS = 256;          // dW + optimizer kernel: 4 waves, one 16x16 tile each
-
-#define MFMA16(A_, B_, C_) C_ = __builtin_amdgcn_mfma_f32_16x16x4f32(A_, B_, C_, 0, 0, 0)
-
-// Workgroup barrier that orders LDS traffic only: outstanding global STORES keep draining in the
-// background (a __syncthreads() would wait for them: one memory round trip per layer).
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0) only (vmcnt / expcnt fields at their maxima)
-    __builtin_amdgcn_s_barrier();
-}
-
-// Weight image in LDS ("k-quad interleaved"): element W[kf][nf] (kf = fan-in index, nf = fan-out index) lives at
-//   ((kf >> 2) * nn + nf) * 4 + (kf & 3)      floats, nn = rup16(fan_out) + 1 (odd -> conflict-free strided reads)
-// Forward  (sum over kf): a lane's four k values are contiguous       -> ONE ds_read_b128.
-// Backward (sum over nf): a lane's four k values are 16 bytes apart   -> ds_read with immediate offsets.
-//
-// Global activations / gradients for the weight-gradient kernel are "blocked transposed": [row block of 16][feature][16
-// rows].  A lane's four rows of one column are one 16-byte store, a wave's store covers 1 KiB contiguous, and the
-// weight-gradient kernel's MFMA fragments are 1 KiB contiguous loads of the same buffer.
-
-#ifdef SMRT_STAMPS
-#define STAMP() do { __syncthreads(); if (a.dbg && blockIdx.x == 0 && tid == 0) { a.dbg[stamp_i] = wall_clock64(); a.dbg[32 + stamp_i] = clock64(); } ++stamp_i; } while (0)
-#define STAMP_NS() do { if (a.dbg && blockIdx.x == 0 && tid == 0 && stamp_i < 31) { a.dbg[stamp_i] = wall_clock64(); a.dbg[32 + stamp_i] = clock64(); } ++stamp_i; } while (0)
-#else
-#define STAMP() do { } while (0)
-#define STAMP_NS() do { } while (0)
-#endif
-
-// NB 16-wide k-blocks of one 16x16 output tile: every LDS fragment read first, then the MFMAs (4 independent chains).
-// ap: this lane's A fragment (activations [row c][k = 4 q ..], k contiguous: one ds_read_b128 per k-block).
-// bp: this lane's weight fragment; !TRANS: one ds_read_b128 per k-block, `bstep` floats apart;
-//     TRANS: the lane's four k values are 4 floats apart (k-quad interleaved image), k-blocks 64 floats apart.
-template <int NB, bool TRANS>
-__device__ __forceinline__ void k_chunk(const float* ap, const float* bp, int bstep,
-                                        f32x4& acc0, f32x4& acc1, f32x4& acc2, f32x4& acc3) {
-    f32x4 av[NB], bv[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        // (the two layouts request their operands in opposite order: with a common first instruction hipcc hoists that
-        // read above the branch that selects the layout, and a read pending from another block makes it wait for ALL reads)
-        if constexpr (TRANS) {
-            const float* p = bp + 64 * j;
-            bv[j][0] = p[0]; bv[j][1] = p[4]; bv[j][2] = p[8]; bv[j][3] = p[12];
-            av[j] = *reinterpret_cast<const f32x4*>(ap + 16 * j);
-        } else {
-            av[j] = *reinterpret_cast<const f32x4*>(ap + 16 * j);
-            bv[j] = *reinterpret_cast<const f32x4*>(bp + j * bstep);
-        }
-        // Pin "reads in consumption order, all requested before the first MFMA".  Left alone, hipcc either sinks each
-        // LDS read to just before its MFMA or issues the reads in an order of its own, and then the first MFMA waits
-        // for (nearly) all of them; pinned, the waits count down lgkmcnt(2 NB - 2), (2 NB - 4), ...
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        MFMA16(av[j][0], bv[j][0], acc0); MFMA16(av[j][1], bv[j][1], acc1);
-        MFMA16(av[j][2], bv[j][2], acc2); MFMA16(av[j][3], bv[j][3], acc3);
-    }
-}
-
-#define UNI(x) __builtin_amdgcn_readfirstlane(x)
 
 __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs a) {
     extern __shared__ __align__(16) float lds[];
@@ -203,165 +128,19 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
     const int s_z = a.s_z;
 
     // ---- every GEMM stage (forward layers, then backward through the activations) runs through this one body
+    StageCtx sx;
+    sx.lds = lds; sx.wave = wave; sx.c = c; sx.q = q; sx.tid = tid; sx.rows_here = rows_here; sx.Z = Z; sx.s_z = s_z;
+    sx.lo = lo; sx.hi = hi; sx.inv_batch = inv_batch; sx.es = es; sx.zs = zs; sx.Zb_g = a.Zb_g; sx.blk = blockIdx.x;
     int4 d0 = sdesc[0], d1 = sdesc[1], d2 = sdesc[2], d3 = sdesc[3], d4 = sdesc[4];
 #pragma unroll 1
     for (int st = 0; st < a.n_stages; ++st) {
-        const int in_off = UNI(d0.x), sin = UNI(d0.y), K16 = UNI(d0.z), w_off = UNI(d0.w);
-        const int nn = UNI(d1.x), N = UNI(d1.y), kind = UNI(d1.z), act = UNI(d1.w);
-        const int out_off = UNI(d2.x), s_out = UNI(d2.y), b_off = UNI(d2.z), aux_off = UNI(d2.w);
-        const int s_aux = UNI(d3.x), NF = UNI(d3.y), trans = UNI(d3.z);
-        gfloat* gblk = (gfloat*)(((unsigned long long)(unsigned)UNI(d4.y) << 32) | (unsigned)UNI(d4.x))
-                       + (long)blockIdx.x * NF * 16;
-        const int N16 = (N + 15) & ~15;
-        const float* ap = lds + in_off + c * sin + 4 * q;
         // the next stage's record is fetched now (the table has room for a read past the last stage)
         const int4 e0 = sdesc[5 * st + 5], e1 = sdesc[5 * st + 6], e2 = sdesc[5 * st + 7], e3 = sdesc[5 * st + 8],
                    e4 = sdesc[5 * st + 9];
-
-#pragma unroll 1
-        for (int n0 = wave * 16; n0 < N16; n0 += 16 * FWAVES) {
-            const int n = n0 + c;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-            // k runs in chunks of NB 16-wide k-blocks, NB a compile-time 8 / 4 / 2 / 1: a chunk is straight-line code -- ALL its
-            // fragments are requested first, then its 4 NB MFMAs run into 4 independent chains while the later reads are
-            // still landing (the compiler counts lgkmcnt down block by block; with run-time guards around the blocks it
-            // waited for every read before the first MFMA and copied the fragment registers around the guards).  Nets on
-            // this path have K in {16, 32, 64, 128} almost always, i.e. exactly one chunk per stage.
-            const int nb_all = K16 >> 4;
-            const float* apc = ap;
-            const float* bp = trans ? lds + w_off + ((((n >> 2) * nn) + 4 * q) << 2) + (n & 3)     // Wop[k][n] = W[kf = n][nf = k]
-                                    : lds + w_off + ((q * nn + n) << 2);                          // Wop[k][n] = W[kf = k][nf = n]
-            const int bstep = trans ? 64 : (nn << 4);                                             // floats per 16 k
-            int left = nb_all;
-#pragma unroll 1
-            for (; left >= 8; left -= 8) {
-                if (trans) k_chunk<8, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                else       k_chunk<8, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                apc += 128; bp += 8 * bstep;
-            }
-            if (left & 4) {
-                if (trans) k_chunk<4, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                else       k_chunk<4, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                apc += 64; bp += 4 * bstep;
-            }
-            if (left & 2) {
-                if (trans) k_chunk<2, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                else       k_chunk<2, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                apc += 32; bp += 2 * bstep;
-            }
-            if (left & 1) {
-                if (trans) k_chunk<1, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                else       k_chunk<1, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-            }
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
-            // rows 4q .. 4q+3 of column n.  Workspace rows are padded to a multiple of 16, so rows past the batch are
-            // computed and stored like the others (their dPre is forced to 0, nothing reads them).
-            float* o = lds + out_off + (4 * q) * s_out + n;
-            gfloat* g = gblk + n * 16 + 4 * q;
-            if (kind <= FK_FWD_HEADS) {
-                // y = act(x.W + b)                                                     layer.py:368
-                if (n < N) {
-                    const float bcol = lds[b_off + 4 * n];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += bcol;
-                    act_fwd4(act, v);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r * s_out] = v[r];
-                    *(gf32x4*)g = f32x4{v[0], v[1], v[2], v[3]};
-                }
-            } else if (kind == FK_FWD_BCE) {
-                // sigmoid output + clipped Bernoulli NLL + dL/dpre (layer.py:333-338, _ae_utils.py:31-32)
-                if (n < N) {
-                    const float bcol = lds[b_off + 4 * n];
-                    const float* xr = lds + aux_off + (4 * q) * s_aux + n;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool valid = (4 * q + r) < rows_here;
-                        const float p = fast_sigmoid(v[r] + bcol);
-                        const float x = xr[r * s_aux];
-                        const float pl = fmaxf(p, lo), pc = fminf(pl, hi), om = 1.0f - pc;
-                        const float term = x * __logf(pc) + (1.0f - x) * __logf(om);
-                        bce -= valid ? term : 0.0f;
-                        // TF clip_by_value gradient gate: Maximum passes where p >= lo, Minimum where max(p,lo) <= hi
-                        const bool pass = valid && (p >= lo) && (pl <= hi);
-                        const float dp = pass ? -(x * __builtin_amdgcn_rcpf(pc) - (1.0f - x) * __builtin_amdgcn_rcpf(om)) * inv_batch : 0.0f;
-                        v[r] = valid ? dp * p * (1.0f - p) : 0.0f;
-                        o[r * s_out] = v[r];
-                    }
-                    *(gf32x4*)g = f32x4{v[0], v[1], v[2], v[3]};
-                }
-            } else if (kind == FK_BWD_ACT) {
-                // dPre_prev = (dPre . W^T) * act'(y_prev); pad columns come out as exact zeros (zero weights, zero y)
-                const float* po = lds + aux_off + (4 * q) * s_aux + n;
-                float yv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) yv[r] = po[r * s_aux];
-                act_bwd4(act, yv, v);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r * s_out] = v[r];
-                *(gf32x4*)g = f32x4{v[0], v[1], v[2], v[3]};
-            } else {
-                // FK_BWD_LATENT: v = dL/dz through the reparameterisation and the KL term into both heads
-                //   dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B     layer.py:279, _ae_utils.py:49
-                if (n < N) {
-                    const float* po = lds + aux_off + (4 * q) * s_aux + n;
-                    const float* er = es + (4 * q) * s_z + n;
-                    float mu[4], ls[4], g_mu[4], g_ls[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        mu[r] = po[r * s_aux];
-                        ls[r] = po[r * s_aux + Z];
-                        const float e = er[r * s_z];
-                        const float el = __expf(ls[r]);
-                        g_mu[r] = v[r] + mu[r] * inv_batch;
-                        g_ls[r] = v[r] * e * el + (el * el - 1.0f) * inv_batch;
-                    }
-                    act_bwd4(act, mu, g_mu);
-                    act_bwd4(act, ls, g_ls);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool valid = (4 * q + r) < rows_here;
-                        g_mu[r] = valid ? g_mu[r] : 0.0f;
-                        g_ls[r] = valid ? g_ls[r] : 0.0f;
-                        o[r * s_out] = g_mu[r];
-                        o[r * s_out + Z] = g_ls[r];
-                    }
-                    *(gf32x4*)g = f32x4{g_mu[0], g_mu[1], g_mu[2], g_mu[3]};
-                    *(gf32x4*)(g + Z * 16) = f32x4{g_ls[0], g_ls[1], g_ls[2], g_ls[3]};
-                }
-            }
-        }
-        if (kind == FK_BWD_LATENT) {
-            // the next stage reads k up to rup16(2Z): clear the tail this stage did not write
-            const int wrote = 2 * Z, tail = ((wrote + 15) & ~15) - wrote;
-            for (int i = tid; i < FTM * tail; i += FTHREADS) {
-                const int r = i / tail;
-                lds[out_off + r * s_out + wrote + (i - r * tail)] = 0.f;
-            }
-        }
+        const int kind = run_stage<1>(d0, d1, d2, d3, d4, sx, bce);
         STAMP_NS();
         lds_barrier();
-        if (kind == FK_FWD_HEADS) {
-            // z = mu + eps * exp(log_sigma)  (layer.py:279) and the KL row terms (_ae_utils.py:49)
-            const float* o = lds + out_off;
-            float* zg = a.Zb_g + (long)blockIdx.x * ((Z + 15) & ~15) * 16;    // blocked transposed [rup16(Z)][16]
-            for (int i = tid; i < FTM * Z; i += FTHREADS) {
-                const int r = i / Z, k = i - r * Z;
-                float z = 0.0f;                                              // finite filler for the padded rows
-                if (r < rows_here) {
-                    const float mu = o[r * s_out + k], ls = o[r * s_out + Z + k];
-                    const float e = es[r * s_z + k];                         // staged by the prologue
-                    const float el = __expf(ls);
-                    z = mu + e * el;
-                    zs[r * s_z + k] = z;
-                    kl += -0.5f * (1.0f + 2.0f * ls - mu * mu - el * el);
-                }
-                zg[k * 16 + r] = z;
-            }
-            lds_barrier();
-        }
+        if (kind == FK_FWD_HEADS) reparam_after_heads<1>(d2, sx, kl);
         d0 = e0; d1 = e1; d2 = e2; d3 = e3; d4 = e4;
     }
     STAMP();
@@ -393,44 +172,6 @@ int fused_set_max_lds(int bytes) {
 // Weight + bias gradients of every layer with the optimizer fused into the epilogue.
 // One wave per 16x16 tile of  [X | 1]^T . dPre ; K = rows of the mini-batch (no split).
 // =====================================================================================
-__device__ __forceinline__ float opt_apply(int opt, float lr, float alpha, float w, float g, float& s0, float& s1) {
-    switch (opt) {
-        case 1:     // RMSProp: decay .9, momentum 0, eps 1e-10 (rms slot starts at 1); v_rsq_f32 is 1 ulp
-            s0 = s0 + (g * g - s0) * (1.0f - 0.9f);
-            s1 = s1 * 0.0f + lr * g * __builtin_amdgcn_rsqf(s0 + 1e-10f);
-            return w - s1;
-        case 2:     // Adam
-            s0 = s0 + (g - s0) * (1.0f - 0.9f);
-            s1 = s1 + (g * g - s1) * (1.0f - 0.999f);
-            return w - alpha * s0 / (sqrtf(s1) + 1e-8f);
-        case 3: case 6:   // Adagrad / ProximalAdagrad(l1 = l2 = 0)
-            s0 = s0 + g * g;
-            return w - lr * g / sqrtf(s0);
-        case 4: {   // Adadelta: rho .95, eps 1e-8
-            s0 = s0 * 0.95f + g * g * (1.0f - 0.95f);
-            const float upd = sqrtf(s1 + 1e-8f) / sqrtf(s0 + 1e-8f) * g;
-            s1 = s1 * 0.95f + upd * upd * (1.0f - 0.95f);
-            return w - lr * upd;
-        }
-        default:    // SGD / ProximalGradientDescent(l1 = l2 = 0)
-            return w - lr * g;
-    }
-}
-
-// Four elements at once with ONE (uniform) switch around them.
-__device__ __forceinline__ void opt_apply4(int opt, float lr, float alpha, const float (&w)[4], const float (&g)[4],
-                                           float (&s0)[4], float (&s1)[4], float (&wn)[4]) {
-    switch (opt) {
-#define SMRT_OPT_CASE(K) _Pragma("unroll") for (int r = 0; r < 4; ++r) wn[r] = opt_apply(K, lr, alpha, w[r], g[r], s0[r], s1[r]); break
-        case 1: SMRT_OPT_CASE(1);
-        case 2: SMRT_OPT_CASE(2);
-        case 3: case 6: SMRT_OPT_CASE(3);
-        case 4: SMRT_OPT_CASE(4);
-        default: SMRT_OPT_CASE(0);
-#undef SMRT_OPT_CASE
-    }
-}
-
 __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs a) {
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63;

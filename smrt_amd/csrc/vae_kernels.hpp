@@ -208,6 +208,32 @@ struct DwSlabArgs {            // weight-gradient tiles of a row range into grad
     float* G; long slab_stride;
 };
 void launch_fused_dw_slab(hipStream_t s, const DwSlabArgs& a, int splits);
+// Persistent whole-epoch training kernel (persist_train.hip)
+struct PersistArgs {
+    FusedStage stages[2 * MAX_LAYERS];    // the same records as the per-launch kernel
+    int n_stages;
+    int G;                                // compute workgroups (blockIdx < G); the rest of the grid are owner workgroups
+    int NL, L, Z, D;
+    const float* X; long ldx; long n_rows; int batch, n_steps;    // the epoch: n_steps contiguous mini-batches, ragged tail last
+    float* Wimg; int img_total;           // LDS-image twin: read by every compute workgroup each step, written by the tile owners
+    float* W; float* s0; float* s1;       // flat parameter / slot buffers: read at launch start, written at launch end
+    const DwTile* tiles; int total_tiles;
+    float* XT; float* Zb_g;               // blocked transposed X tile copy and z (the stage records carry the other buffers)
+    int cap_blocks;                       // 16-row blocks the blocked transposed workspace holds
+    unsigned* cnt;                        // 64 words zeroed before every launch: [0] rows published, [16] weights, [32] error
+    int lds_x, s_x, lds_z, lds_e, s_z, lds_total;
+    uint64_t seed; DevState* st;
+    float lo, hi;
+    float* bce_p; float* kl_p;            // cost partials of the LAST mini-batch, one per compute workgroup
+    float* l2_p;                          // ... and its L2 term, one per owner workgroup
+    int opt, clip, has_l2;
+    float lr, l2, gmin, gmax;
+    unsigned long long* dbg;              // diagnostic builds only (-DSMRT_STAMPS): phase time stamps, step 4
+};
+void launch_persist_train(hipStream_t s, const PersistArgs& a, int n_workgroups);
+int  persist_set_max_lds(int bytes);
+int  persist_owner_workgroups(int total_tiles);     // one owner wave per 16x16 weight-gradient tile, 4 per workgroup
+
 // Fused inference (encode / decode / generate) for nets whose weights fit in LDS: fused_small.hip
 struct InferStage { int K16, N, N16, w_off, nn, b_off, act, pad; };   // image offsets relative to the staged range
 struct InferArgs {

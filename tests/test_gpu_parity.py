@@ -382,3 +382,82 @@ def test_generate_across_z_chunks_is_position_independent():
         assert torch.equal(big[start:start + cnt], part), "rows %d.." % start
     assert bool(torch.isfinite(big).all())
     h.close()
+
+
+# ---------------------------------------------------------------------------------------- persistent whole-epoch kernel
+def _persist_pair(monkeypatch, D, hidden, Z, act, opt, max_batch, rs, lr=0.01, l2=1e-4, clip=True, seed=11):
+    """(oracle, handle on the persistent path, handle on the two-kernel path) with the same injected weights."""
+    o = _oracle(D, hidden, Z, act=act, opt=opt, lr=lr, l2=l2, clip=clip, seed=seed, rs=rs)
+    hs = []
+    for persist in ("1", "0"):
+        monkeypatch.setenv("SMRT_HIP_PERSIST", persist)
+        h = _handle(D, hidden, Z, act=act, opt=opt, lr=lr, l2=l2, clip=clip, seed=seed, max_batch=max_batch)
+        h.set_params(flatten_params(o.params))
+        hs.append(h)
+    return o, hs[0], hs[1]
+
+
+@pytest.mark.parametrize("D,hidden,Z,act,opt,n,B", [
+    (64, [128], 16, "sigmoid", "rms_prop", 1000, 128),     # the bench net: 8 compute + 28 owner workgroups, ragged tail of 104
+    (64, [128], 16, "sigmoid", "adam", 300, 128),          # Adam: beta powers kept per owner wave; tail of 44 rows (5 workgroups idle)
+    (24, [16], 4, "tanh", "sgd", 150, 64),                 # batches 64, 64, 22: the last has rows in 2 of 4 workgroups
+    (12, [7], 3, "relu", "adagrad", 37, 10),               # ONE compute workgroup, ragged widths (partial k-quads, bias quads)
+    (30, [20, 12], 5, "elu", "adadelta", 700, 500),        # 32 compute workgroups (batch 500), two hidden layers
+    (40, [72], 6, "identity", "proximal-adagrad", 130, 130),   # a single mini-batch per epoch
+])
+def test_persistent_epochs_match_two_kernel_path_and_oracle(monkeypatch, kernel_path, D, hidden, Z, act, opt, n, B):
+    """One launch per epoch (persist_train.hip: compute workgroups + owner workgroups exchanging through L2) against the
+    two-kernel step and against the oracle's fit: epoch costs, parameters, both optimizer slots, the step counter."""
+    if kernel_path != "fused":
+        pytest.skip("the persistent kernel belongs to the LDS-resident (fused) path")
+    rs = np.random.RandomState(n)
+    o, hp, h2 = _persist_pair(monkeypatch, D, hidden, Z, act, opt, B, rs)
+    X = rs.uniform(0, 1, size=(n, D))
+    nb = (n + B - 1) // B
+    cp, _ = hp.train_epochs(X, B, 3)
+    c2, _ = h2.train_epochs(X, B, 3)
+    assert hp.last_epoch_launches == 2, hp.last_epoch_launches           # the persistent launch + the cost of the last batch
+    assert h2.last_epoch_launches >= 2 * nb
+    o.fit(X, n_epochs=3, batch_size=B)
+    np.testing.assert_allclose(cp, np.asarray(o.epoch_costs_, np.float32), rtol=RTOL)
+    np.testing.assert_allclose(cp, c2, rtol=2e-5)
+    _close(hp.get_params(), flatten_params(o.params), "persistent params vs oracle")
+    _close(hp.get_params(), h2.get_params(), "persistent vs two-kernel params", rtol=2e-5)
+    for slot in (0, 1):
+        _close(hp.get_opt_state(slot), h2.get_opt_state(slot), "slot %d" % slot, rtol=2e-5)
+    assert hp.step_count == h2.step_count == 3 * nb
+    # a second call continues from the device-resident state (step counter -> Philox stream, Adam powers), and single
+    # steps through the two-kernel path pick up the weights the persistent launch left (flat buffer AND image twin)
+    cp, _ = hp.train_epochs(X, B, 2)
+    c2, _ = h2.train_epochs(X, B, 2)
+    np.testing.assert_allclose(cp, c2, rtol=5e-5)
+    Xs, eps = rs.uniform(0, 1, size=(min(B, 48), D)), rs.normal(size=(min(B, 48), Z))
+    assert np.isclose(hp.train_step(Xs, eps), h2.train_step(Xs, eps), rtol=5e-5)
+    cp, _ = hp.train_epochs(X, B, 1)
+    c2, _ = h2.train_epochs(X, B, 1)
+    np.testing.assert_allclose(cp, c2, rtol=1e-4)
+    _close(hp.get_params(), h2.get_params(), "after epochs, a step, an epoch", rtol=1e-4)
+    mu_p, ls_p = hp.encode(X[:40]); mu_2, ls_2 = h2.encode(X[:40])
+    _close(mu_p, mu_2, "encode after persistent training", rtol=1e-4)
+    hp.close(); h2.close()
+
+
+def test_persistent_early_stopping_and_ineligible_nets(monkeypatch, kernel_path):
+    """Early stopping reads the cost after every persistent launch; dropout nets keep the two-kernel step."""
+    if kernel_path != "fused":
+        pytest.skip("the persistent kernel belongs to the LDS-resident (fused) path")
+    rs = np.random.RandomState(9)
+    D, hidden, Z, n, B = 16, [8], 2, 64, 32
+    o, hp, h2 = _persist_pair(monkeypatch, D, hidden, Z, "sigmoid", "sgd", B, rs, lr=1e-4, seed=5)
+    X = rs.uniform(0, 1, size=(n, D))
+    o.fit(X, n_epochs=30, batch_size=B, early_stopping=True, min_change=0.05)
+    costs, _ = hp.train_epochs(X, B, 30, early_stopping=True, min_change=0.05)
+    assert len(costs) == len(o.epoch_costs_) < 30 and hp.last_epoch_launches == 2
+    np.testing.assert_allclose(costs, np.array(o.epoch_costs_, np.float32), rtol=RTOL)
+    hp.close(); h2.close()
+    monkeypatch.setenv("SMRT_HIP_PERSIST", "1")
+    hd = _handle(D, hidden, Z, drop=0.5, max_batch=B)
+    hd.set_params(flatten_params(o.params))
+    hd.train_epochs(X, B, 2)
+    assert hd.last_epoch_launches > 2
+    hd.close()
