@@ -53,7 +53,7 @@ def main():
     out = {"csrc_hash": csrc_hash(), "command": "python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-balance",
            "units": "bytes per launch; FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled (gfx950 correction)", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
-        if k not in stats or not (k.startswith("fused") or k.startswith("gemm") or k.startswith("dw_") or
+        if k not in stats or not (k.startswith("fused") or k.startswith("persist") or k.startswith("gemm") or k.startswith("dw_") or
                                   k.startswith("optimizer") or k.startswith("finalize")):
             continue
         f = 1024.0 * fetch[k] / max(nf[k], 1)
