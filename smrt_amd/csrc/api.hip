@@ -1185,9 +1185,11 @@ static bool infer_fused_fits(const smrt_vae* h, int l0, int l1) {
 
 // Layers [l0, l1] of a net on the fused path in ONE persistent launch (fused_infer_kernel).  Returns 1 when the launch was
 // enqueued, 0 when this net / call does not qualify (the caller then runs the per-layer GEMM chain), < 0 on error.
+struct GenDraw { uint64_t elem0; float loc, scale; };
 static int infer_fused(smrt_vae* h, int l0, int l1, const float* in, long ldin, long n,
-                       float* out0, long ld0, int split, float* out1, long ld1) {
+                       float* out0, long ld0, int split, float* out1, long ld1, const GenDraw* gen = nullptr) {
     if (!h->fused || !h->Wimg || n <= 0) return 0;
+    if (!in && !(gen && (h->flay[l0].fi & 3) == 0 && (gen->elem0 & 3) == 0)) return 0;   // in-kernel draw: whole Philox blocks only
     const char* e = std::getenv("SMRT_HIP_FUSED_INFER");
     if (e && std::atoi(e) == 0) return 0;
     InferArgs a{};
@@ -1206,6 +1208,7 @@ static int infer_fused(smrt_vae* h, int l0, int l1, const float* in, long ldin, 
     a.tile_stride = std::max(rup16(h->flay[l0].fi), rup16(h->flay[l1].fo)) + 4;
     a.img = h->Wimg + start; a.img_n4 = (end - start) / 4;
     a.in = in; a.ldin = ldin; a.K = h->flay[l0].fi; a.n = n;
+    if (!in) { a.gen_seed = h->cfg.seed; a.gen_elem0 = gen->elem0; a.gen_loc = gen->loc; a.gen_scale = gen->scale; }
     a.out0 = out0; a.ld0 = ld0; a.split = split; a.out1 = out1; a.ld1 = ld1;
     const int N = h->flay[l1].fo;
     a.vec_out = (split >= N && N % 4 == 0 && ld0 % 4 == 0 && ((uintptr_t)out0 & 15) == 0) ? 1 : 0;
@@ -1313,6 +1316,13 @@ int smrt_vae_generate(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc,
     const long ldz = rup4(h->Z);
     const bool fused_ok = h->fused && h->Wimg;
     const long chunk = std::min<long>(n, fused_ok ? INFER_CHUNK_FUSED : INFER_CHUNK);
+    if (fused_ok) {
+        // z drawn inside the persistent decode launch (one launch for the whole call, no z buffer)
+        const GenDraw gd{philox_offset, loc, scale};
+        const int f = infer_fused(h, h->dec0, h->NL - 1, nullptr, 0, n, out_dev, ldo, h->D, nullptr, 0, &gd);
+        if (f < 0) return f;
+        if (f) { HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(h->stream)); return 0; }
+    }
     TRY(ensure_infer(h, chunk, !fused_ok));
     for (long r0 = 0; r0 < n; r0 += chunk) {
         const long rows = std::min<long>(chunk, n - r0);

@@ -496,7 +496,7 @@ __global__ __launch_bounds__(ITHREADS) void fused_infer_kernel(const InferArgs a
         // Rows enter and leave through a wave-private LDS tile so that global traffic is whole rows (16 bytes per lane,
         // consecutive lanes along a row).  Rows past the end shadow the last row (never stored), columns past K are zero.
         // (no integer division: a row takes 4 or 16 lanes, whichever the row length fills)
-        {
+        if (a.in) {
             const int sh = (k4n >= 16) ? 4 : 2, lpr = 1 << sh, rpi = 64 >> sh;         // lanes per row, rows per instruction
             const int lr = lane >> sh, lc = lane & (lpr - 1);
             for (int rr = 0; rr < 16; rr += rpi) {
@@ -509,6 +509,26 @@ __global__ __launch_bounds__(ITHREADS) void fused_infer_kernel(const InferArgs a
                     v[1] = (c4 + 1 < K) ? v[1] : 0.f; v[2] = (c4 + 2 < K) ? v[2] : 0.f; v[3] = (c4 + 3 < K) ? v[3] : 0.f;
                     *reinterpret_cast<f32x4*>(tile + r * s_t + c4) = v;
                 }
+            }
+        } else {
+            // generate: the 16 latent rows are drawn here, one Philox block = four consecutive normals per lane and round
+            // (K = Z is a multiple of 4 and the stream offset is block-aligned: host-checked) -- no z buffer, no launch of
+            // its own in front of this one
+            const int kq_n = K >> 2;
+            for (int i = lane; i < 16 * k4n; i += 64) {
+                const int r = i / k4n, kq = i - r * k4n;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kq < kq_n && r0 + r < a.n) {
+                    const uint64_t q = ((a.gen_elem0 + (uint64_t)(r0 + r) * K) >> 2) + kq;
+                    const Philox4 p = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 0u, STREAM_GENERATE,
+                                                    (uint32_t)a.gen_seed, (uint32_t)(a.gen_seed >> 32));
+                    float n0, n1, n2, n3;
+                    box_muller(p.x, p.y, n0, n1);
+                    box_muller(p.z, p.w, n2, n3);
+                    v = f32x4{a.gen_loc + a.gen_scale * n0, a.gen_loc + a.gen_scale * n1,
+                              a.gen_loc + a.gen_scale * n2, a.gen_loc + a.gen_scale * n3};
+                }
+                *reinterpret_cast<f32x4*>(tile + r * s_t + 4 * kq) = v;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");             // written by other lanes of this wave
