@@ -102,6 +102,18 @@ int  smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t
                            int32_t n_epochs, int32_t early_stopping, float min_change,
                            float* epoch_cost_host, float* epoch_ms_host, int32_t* epochs_done);
 
+/* The _train loops of SEVERAL handles side by side (no counterpart in the reference, which fits its per-class VAEs one
+ * after the other, smrt/balance/smrt.py:197-223): handle k trains on X_dev[k] ([n_rows[k]][ldx[k]]) with the reference's
+ * schedule, exactly as n smrt_vae_train_epochs calls would -- same kernels, same numbers -- but the launches of one kernel
+ * at the same position of the handles' steps are issued as ONE grouped launch (gridDim.z = handle), so the small grids of
+ * a default-batch step fill the GPU together.  No early stopping.  epoch_cost_host [n_handles][n_epochs];
+ * epoch_ms_host [n_epochs] (the epochs are shared).  Returns 0, < 0 on error, or 1 when grouping does not apply to these
+ * handles (LDS-resident nets, mini-batches beyond 512 rows, different devices, a single handle): nothing was done and the
+ * caller trains them one by one. */
+int  smrt_vae_train_epochs_multi(smrt_vae** hs, int32_t n_handles, const float* const* X_dev, const int64_t* ldx,
+                                 const int64_t* n_rows, int32_t batch_size, int32_t n_epochs,
+                                 float* epoch_cost_host, float* epoch_ms_host);
+
 /* Data-parallel halves of a step (no reference counterpart): grad_step leaves
  * [internal-layout gradient sums | sum of row losses] scaled by 1/global_rows in grads_dev
  * (smrt_vae_dp_count floats) so ranks can all-reduce(SUM) it; apply_grads adds L2, clips, updates.

@@ -23,7 +23,8 @@ OPTIMIZER_IDS = {"sgd": 0, "rms_prop": 1, "adam": 2, "adagrad": 3, "adadelta": 4
 EXPORTS = [
     "smrt_vae_create", "smrt_vae_destroy", "smrt_vae_param_count", "smrt_vae_set_params",
     "smrt_vae_get_params", "smrt_vae_get_opt_state", "smrt_vae_reset_opt_state", "smrt_vae_step_count",
-    "smrt_vae_set_dropout_masks", "smrt_vae_train_step", "smrt_vae_train_epochs", "smrt_vae_dp_count",
+    "smrt_vae_set_dropout_masks", "smrt_vae_train_step", "smrt_vae_train_epochs", "smrt_vae_train_epochs_multi",
+    "smrt_vae_dp_count",
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_generate_noalloc", "smrt_vae_generate_noalloc_max_rows", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
@@ -88,6 +89,8 @@ def load():
     lib.smrt_vae_set_dropout_masks.argtypes = [vp, f32p, i64]
     lib.smrt_vae_train_step.argtypes = [vp, vp, i64, i32, vp, f32p, f32p]
     lib.smrt_vae_train_epochs.argtypes = [vp, vp, i64, i64, i32, i32, i32, C.c_float, f32p, f32p, C.POINTER(i32)]
+    lib.smrt_vae_train_epochs_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), i32, i32,
+                                                f32p, f32p]
     lib.smrt_vae_grad_step.argtypes = [vp, vp, i64, i32, i64, i64, vp, vp]
     lib.smrt_vae_apply_grads.argtypes = [vp, vp, f32p]
     lib.smrt_vae_grad_step_async.argtypes = [vp, vp, i64, i32, i64, i64, vp, vp]
@@ -319,6 +322,28 @@ def smote_rows(X_dev, base_idx, nbr_idx, r, mode="perturb", to_host=True):
                                       0 if mode == "perturb" else 1, out.data_ptr(), out.stride(0),
                                       C.c_void_p(stream.cuda_stream)), "smrt_smote_rows_f64")
     return out.cpu().numpy() if to_host else out
+
+
+def train_epochs_multi(handles, Xs, batch_size, n_epochs):
+    """The ``_train`` loops of several handles side by side with grouped launches (``smrt_vae_train_epochs_multi``).
+
+    ``Xs[k]`` is ``(tensor, ld)`` on the handles' GPU.  Returns ``(costs [n_handles][n_epochs], epoch_ms [n_epochs])``, or
+    ``None`` when the library declines (nets on the LDS-resident paths, batches beyond 512 rows, a single handle): the
+    caller then trains the handles one by one."""
+    n = len(handles)
+    lib = load()
+    hs = (C.c_void_p * n)(*[h._live() for h in handles])
+    xp = (C.c_void_p * n)(*[C.c_void_p(X[0].data_ptr()) for X in Xs])
+    ld = (C.c_int64 * n)(*[int(X[1]) for X in Xs])
+    nr = (C.c_int64 * n)(*[int(X[0].shape[0]) for X in Xs])
+    costs = np.zeros((n, int(n_epochs)), dtype=np.float32)
+    ms = np.zeros(int(n_epochs), dtype=np.float32)
+    sync_torch_stream(handles[0].device)
+    rc = lib.smrt_vae_train_epochs_multi(hs, n, xp, ld, nr, int(batch_size), int(n_epochs), _f32p(costs), _f32p(ms))
+    if rc == 1:
+        return None
+    _check(rc, "smrt_vae_train_epochs_multi")
+    return costs, ms
 
 
 class VaeHandle(object):

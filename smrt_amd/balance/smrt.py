@@ -30,6 +30,7 @@ import numpy as np
 from .. import _hip
 from ..autoencode import VariationalAutoEncoder
 from ..autoencode.topography import resolve_latent
+from ..autoencode.vae import fit_group
 from ..utils import DEFAULT_SEED, get_random_state
 from .base import validate_X_y_ratio_classes
 
@@ -83,6 +84,17 @@ def _exchange_block(dist, slab_rows, src, mine, rows_dev=None):
     dist.broadcast(t, src=src)
     if not mine:
         view.copy_(t)
+
+
+class _GroupMember(object):
+    """``result()`` of one estimator of a ``fit_group`` task (the interface of a future)."""
+
+    def __init__(self, group_future, estimator):
+        self.group_future, self.estimator = group_future, estimator
+
+    def result(self):
+        self.group_future.result()
+        return self.estimator
 
 
 def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, balance_ratio=0.2,
@@ -188,8 +200,12 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
     try:
         if n_fresh:
             from concurrent.futures import ThreadPoolExecutor
-            pool = ThreadPoolExecutor(max_workers=min(n_threads, n_fresh))
-            fits = [None if f is None else pool.submit(f.fit, X_sub) for f, X_sub in zip(fits, subs)]
+            # ONE background task fits every class this rank owns: grouped launches where the library can group them
+            # (fit_group), one host thread and HIP stream per class otherwise; the main thread goes on with the draws
+            pool = ThreadPoolExecutor(max_workers=1)
+            fresh_jobs = [j for j, f in enumerate(fits) if f is not None]
+            group = pool.submit(fit_group, [fits[j] for j in fresh_jobs], [subs[j] for j in fresh_jobs], n_threads)
+            fits = [None if f is None else _GroupMember(group, f) for f in fits]
 
         synth.fill(0.0)                      # touch the slab's pages while the fits run, not while they are waited for
         # ---- the shared stream, in class order (smrt.py:226-238 via autoencoder.py:519-572)

@@ -18,6 +18,17 @@ static thread_local std::string g_err;
 namespace smrt {
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
 thread_local GraphBuild g_build;
+thread_local Recorder g_record;
+// kernel -> grouped twin (filled by static registration objects next to the kernels; read-only afterwards)
+static std::vector<std::pair<const void*, MultiInfo>>& multi_registry() {
+    static std::vector<std::pair<const void*, MultiInfo>> r;
+    return r;
+}
+void smrt_register_multi(const void* kernel, const MultiInfo& info) { multi_registry().emplace_back(kernel, info); }
+const MultiInfo* smrt_multi_of(const void* kernel) {
+    for (auto& e : multi_registry()) if (e.first == kernel) return &e.second;
+    return nullptr;
+}
 }
 static int fail(int code, const std::string& m) { g_err = m; return code; }
 int smrt_set_error(int code, const std::string& m) { return fail(code, m); }     // for diag.hip
@@ -1060,6 +1071,150 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     h->steps += (int64_t)done * nb;
     if (epochs_done) *epochs_done = done;
     return 0;
+}
+
+// ---- several handles trained side by side with grouped launches (vae_kernels.hpp: MultiSlot / Recorder) ------------
+// Returns 1 ("declined", nothing done) when grouping does not apply: a handle on the LDS-resident paths (its steps are one
+// or two launches already), mini-batches beyond the small-batch kernels, handles on different devices.
+int smrt_vae_train_epochs_multi(smrt_vae** hs, int32_t n_handles, const float* const* X_dev, const int64_t* ldx,
+                                const int64_t* n_rows, int32_t batch_size, int32_t n_epochs,
+                                float* epoch_cost_host, float* epoch_ms_host) {
+    if (!hs || !X_dev || !ldx || !n_rows || n_handles < 1) return fail(-1, "smrt_vae_train_epochs_multi: null argument");
+    if (batch_size < 1 || n_epochs < 1) return fail(-1, "smrt_vae_train_epochs_multi: bad sizes");
+    for (int k = 0; k < n_handles; ++k) {
+        smrt_vae* h = hs[k];
+        if (!h) return fail(-1, "smrt_vae_train_epochs_multi: null handle");
+        if (n_rows[k] < 1) return fail(-1, "smrt_vae_train_epochs_multi: bad sizes");
+        TRY(check_mat(X_dev[k], ldx[k], h->D, "smrt_vae_train_epochs_multi: X"));
+        if (h->device != hs[0]->device || h->fused || h->prof || std::min<int64_t>(batch_size, n_rows[k]) > SMALL_M_MAX)
+            return 1;
+        for (int j = 0; j < k; ++j) if (hs[j] == h) return fail(-1, "smrt_vae_train_epochs_multi: a handle appears twice");
+    }
+    if (n_handles < 2) return 1;
+    HIPC(hipSetDevice(hs[0]->device));
+    hipStream_t stream = hs[0]->stream;
+    for (int k = 0; k < n_handles; ++k) {
+        HIPC(hipStreamSynchronize(hs[k]->stream));
+        TRY(ensure_train(hs[k], (int)std::min<int64_t>(batch_size, n_rows[k])));
+        TRY(ensure_cost(hs[k], n_epochs + 1));
+    }
+    // 1. record every handle's epoch, step by step (nothing is launched)
+    std::vector<std::vector<std::vector<RecordedLaunch>>> rec(n_handles);       // [handle][step][launch]
+    size_t max_steps = 0;
+    for (int k = 0; k < n_handles; ++k) {
+        smrt_vae* h = hs[k];
+        const long nb = (n_rows[k] + batch_size - 1) / batch_size;
+        rec[k].resize(nb);
+        for (long b = 0; b < nb; ++b) {
+            const long r0 = b * batch_size;
+            const int rows = (int)std::min<long>(batch_size, n_rows[k] - r0);
+            StepOut o{(b == nb - 1) ? h->cost_dev : nullptr, nullptr, nullptr};
+            g_record.out = &rec[k][b];
+            const int rc = enqueue_step(h, X_dev[k] + r0 * ldx[k], ldx[k], rows, 1.0f / (float)rows, 0, nullptr, 0, o);
+            g_record.out = nullptr;
+            if (rc) return rc;
+        }
+        max_steps = std::max(max_steps, (size_t)nb);
+    }
+    // 2. merge position by position: launches of one kernel at the same (step, position) become one grouped launch
+    struct Merged { const MultiInfo* info; dim3 grid, block; unsigned shmem; size_t table_off; std::function<void(hipStream_t)> plain; };
+    std::vector<Merged> plan;
+    std::vector<char> table;
+    for (size_t sidx = 0; sidx < max_steps; ++sidx) {
+        size_t max_len = 0;
+        for (int k = 0; k < n_handles; ++k) if (sidx < rec[k].size()) max_len = std::max(max_len, rec[k][sidx].size());
+        for (size_t j = 0; j < max_len; ++j) {
+            std::vector<RecordedLaunch*> here;
+            for (int k = 0; k < n_handles; ++k)
+                if (sidx < rec[k].size() && j < rec[k][sidx].size()) here.push_back(&rec[k][sidx][j]);
+            std::vector<bool> done(here.size(), false);
+            for (size_t i = 0; i < here.size(); ++i) {
+                if (done[i]) continue;
+                std::vector<RecordedLaunch*> grp{here[i]};
+                done[i] = true;
+                const MultiInfo* info = here[i]->args.empty() ? nullptr : smrt_multi_of(here[i]->kernel);
+                if (info)
+                    for (size_t i2 = i + 1; i2 < here.size(); ++i2)
+                        if (!done[i2] && here[i2]->kernel == here[i]->kernel && !here[i2]->args.empty() &&
+                            here[i2]->shmem == here[i]->shmem && here[i2]->block.x == here[i]->block.x &&
+                            here[i2]->grid.z == 1 && here[i]->grid.z == 1) { grp.push_back(here[i2]); done[i2] = true; }
+                if (!info || grp.size() < 2) {
+                    for (RecordedLaunch* r : grp) plan.push_back(Merged{nullptr, r->grid, r->block, r->shmem, 0, r->plain});
+                    continue;
+                }
+                Merged m{info, dim3(0, 0, (unsigned)grp.size()), grp[0]->block, grp[0]->shmem, table.size(), nullptr};
+                for (RecordedLaunch* r : grp) {
+                    m.grid.x = std::max(m.grid.x, r->grid.x); m.grid.y = std::max(m.grid.y, r->grid.y);
+                    const size_t at = table.size();
+                    table.resize(at + info->slot_size, 0);
+                    std::memcpy(table.data() + at, r->args.data(), info->arg_size);
+                    const unsigned g2[2] = {r->grid.x, r->grid.y};
+                    std::memcpy(table.data() + at + info->gx_off, g2, sizeof(g2));
+                }
+                plan.push_back(std::move(m));
+            }
+        }
+    }
+    // 3. the tables on the device, the epoch as ONE graph, n_epochs replays
+    char* table_dev = nullptr;
+    if (!table.empty()) {
+        HIPC(hipMalloc((void**)&table_dev, table.size()));
+        if (hipMemcpy(table_dev, table.data(), table.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(table_dev);
+            return fail(-2, "smrt_vae_train_epochs_multi: table upload failed");
+        }
+    }
+    auto issue_all = [&](hipStream_t s) {
+        for (Merged& m : plan) {
+            if (!m.info) { m.plain(s); continue; }
+            std::tuple<const void*> arg((const void*)(table_dev + m.table_off));
+            smrt_issue((void (*)(const void*))m.info->multi, m.grid, m.block, m.shmem, s, arg);
+        }
+    };
+    hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
+    bool graphed = false;
+    if (hs[0]->use_graph && n_epochs > 1 && hipGraphCreate(&graph, 0) == hipSuccess) {
+        g_build = GraphBuild{};
+        g_build.graph = graph;
+        issue_all(stream);
+        const hipError_t e = g_build.err;
+        const long nodes = g_build.nodes;
+        g_build = GraphBuild{};
+        graphed = e == hipSuccess && nodes > 0 && hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (!graphed) (void)hipGetLastError();
+    }
+    std::vector<hipEvent_t> ev(2 * (size_t)n_epochs, nullptr);
+    int rc = 0;
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) rc = fail(-2, "hipEventCreate failed");
+    for (int ep = 0; ep < n_epochs && rc == 0; ++ep) {
+        (void)hipEventRecord(ev[2 * ep], stream);
+        if (graphed) { if (hipGraphLaunch(gexec, stream) != hipSuccess) rc = fail(-2, "grouped epoch graph launch failed"); }
+        else issue_all(stream);
+        (void)hipEventRecord(ev[2 * ep + 1], stream);
+        for (int k = 0; k < n_handles && rc == 0; ++k)
+            if (hipMemcpyAsync(hs[k]->cost_pin + ep, hs[k]->cost_dev, sizeof(float), hipMemcpyDeviceToHost, stream) != hipSuccess)
+                rc = fail(-2, "cost read-back failed");
+    }
+    const hipError_t es = hipStreamSynchronize(stream);
+    if (rc == 0 && es != hipSuccess) rc = fail(-2, std::string("train_epochs_multi sync: ") + hipGetErrorString(es));
+    if (rc == 0) {
+        for (int ep = 0; ep < n_epochs; ++ep) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[2 * ep], ev[2 * ep + 1]);
+            if (epoch_ms_host) epoch_ms_host[ep] = ms;
+            for (int k = 0; k < n_handles; ++k)
+                if (epoch_cost_host) epoch_cost_host[(size_t)k * n_epochs + ep] = hs[k]->cost_pin[ep];
+        }
+        for (int k = 0; k < n_handles; ++k) {
+            hs[k]->steps += (int64_t)n_epochs * ((n_rows[k] + batch_size - 1) / batch_size);
+            hs[k]->last_epoch_launches = (int)plan.size();
+        }
+    }
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (table_dev) (void)hipFree(table_dev);
+    return rc;
 }
 
 int smrt_vae_set_stream(smrt_vae* h, void* hip_stream, int32_t own) {

@@ -127,8 +127,9 @@ __device__ __forceinline__ f32x4v small_tile(const float* __restrict__ A, long l
 }
 
 // ------------------------------------------------------------------ dense layer forward / backward
+// (body shared by the plain kernel and its grouped twin; gx = columns of tiles of THIS problem's grid)
 template <int ALAY, int BLAY, int EPI>
-__global__ __launch_bounds__(256, 2) void small_gemm_kernel(const GemmArgs a) {
+__device__ __forceinline__ void small_gemm_body(const GemmArgs& a, unsigned gx) {
     __shared__ float red[4 * ST * SRED];
     __shared__ float sred[4];
     const int m0 = blockIdx.y * ST, n0 = blockIdx.x * ST;
@@ -226,9 +227,24 @@ __global__ __launch_bounds__(256, 2) void small_gemm_kernel(const GemmArgs a) {
     }
     if constexpr (EPI == EPI_BCE || EPI == EPI_MSE) {
         const float tot = block_sum_256(lsum, sred);
-        if (threadIdx.x == 0) a.partials[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+        if (threadIdx.x == 0) a.partials[blockIdx.y * gx + blockIdx.x] = tot;
     }
 }
+
+template <int ALAY, int BLAY, int EPI>
+__global__ __launch_bounds__(256, 2) void small_gemm_kernel(const GemmArgs a) { small_gemm_body<ALAY, BLAY, EPI>(a, gridDim.x); }
+
+// grouped twin: gridDim.z problems (one per handle), each with its own arguments and grid extent in a device table
+template <int ALAY, int BLAY, int EPI>
+__global__ __launch_bounds__(256, 2) void small_gemm_multi(const MultiSlot<GemmArgs>* __restrict__ t) {
+    const MultiSlot<GemmArgs>& s = t[blockIdx.z];
+    if (blockIdx.x >= s.gx || blockIdx.y >= s.gy) return;
+    small_gemm_body<ALAY, BLAY, EPI>(s.a, s.gx);
+}
+#define SMRT_REG_SMALL(AL, BL, EP) static MultiReg<GemmArgs> reg_small_##AL##BL##EP(small_gemm_kernel<AL, BL, EP>, small_gemm_multi<AL, BL, EP>)
+SMRT_REG_SMALL(INNER, OUTER, EPI_BIAS_ACT); SMRT_REG_SMALL(INNER, OUTER, EPI_BCE); SMRT_REG_SMALL(INNER, OUTER, EPI_MSE);
+SMRT_REG_SMALL(INNER, OUTER, EPI_HEADS_SPLIT); SMRT_REG_SMALL(INNER, INNER, EPI_ACTGRAD); SMRT_REG_SMALL(INNER, INNER, EPI_LATENT);
+#undef SMRT_REG_SMALL
 
 int small_gemm_blocks(const GemmArgs& a) { return ((a.M + ST - 1) / ST) * ((a.N + ST - 1) / ST); }
 
@@ -252,7 +268,7 @@ void launch_small_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a) {
 
 // ------------------------------------------------------------------ weight + bias gradients of every layer, one launch
 // [X | 1]^T . dPre with K = rows of the mini-batch (no split-K: one slab); the virtual ones index gives the bias row.
-__global__ __launch_bounds__(256, 2) void small_dw_kernel(const DwArgs a) {
+__device__ __forceinline__ void small_dw_body(const DwArgs& a) {
     __shared__ float red[4 * ST * SRED];
     const int t = blockIdx.x;
     int li = 0;
@@ -272,6 +288,14 @@ __global__ __launch_bounds__(256, 2) void small_dw_kernel(const DwArgs a) {
         }
     }
 }
+
+__global__ __launch_bounds__(256, 2) void small_dw_kernel(const DwArgs a) { small_dw_body(a); }
+__global__ __launch_bounds__(256, 2) void small_dw_multi(const MultiSlot<DwArgs>* __restrict__ t) {
+    const MultiSlot<DwArgs>& s = t[blockIdx.z];
+    if (blockIdx.x >= s.gx) return;
+    small_dw_body(s.a);
+}
+static MultiReg<DwArgs> reg_small_dw(small_dw_kernel, small_dw_multi);
 
 void launch_small_dw(hipStream_t s, const DwArgs& a) {
     SMRT_LAUNCH(small_dw_kernel, dim3(a.total_tiles), dim3(256), 0, s, a);

@@ -373,34 +373,38 @@ void launch_dw(hipStream_t s, const DwArgs& a, bool big) {
 // =====================================================================================
 // Reparameterisation + KL (forward)
 // =====================================================================================
-__global__ __launch_bounds__(256) void reparam_kernel(const float* __restrict__ ML, long ldml,
-                                                      const float* __restrict__ eps_in,
-                                                      float* __restrict__ Zb, float* __restrict__ Eb, long ldz,
-                                                      int rows, int Z, uint64_t seed, const DevState* st,
-                                                      long row0_global, float* kl_partials) {
+__device__ __forceinline__ void reparam_body(const ReparamArgs& a) {
     __shared__ float red[4];
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int Z = a.Z;
     float kl = 0.f;
-    if (idx < (long)rows * Z) {
+    if (idx < (long)a.rows * Z) {
         const int row = (int)(idx / Z), k = (int)(idx % Z);
-        const float mu = ML[(long)row * ldml + k];
-        const float ls = ML[(long)row * ldml + Z + k];
-        const float e = eps_in ? eps_in[idx]
-                               : philox_normal1(seed, STREAM_EPS, st->step, (uint64_t)(row0_global + row) * Z + k);
-        Zb[(long)row * ldz + k] = mu + e * expf(ls);                       // layer.py:279
-        Eb[(long)row * ldz + k] = e;
+        const float mu = a.ML[(long)row * a.ldml + k];
+        const float ls = a.ML[(long)row * a.ldml + Z + k];
+        const float e = a.eps_in ? a.eps_in[idx]
+                                 : philox_normal1(a.seed, STREAM_EPS, a.st->step, (uint64_t)(a.row0_global + row) * Z + k);
+        a.Zb[(long)row * a.ldz + k] = mu + e * expf(ls);                     // layer.py:279
+        a.Eb[(long)row * a.ldz + k] = e;
         kl = -0.5f * (1.0f + 2.0f * ls - mu * mu - expf(2.0f * ls));       // _ae_utils.py:49
     }
     const float tot = block_sum_256(kl, red);
-    if (threadIdx.x == 0) kl_partials[blockIdx.x] = tot;
+    if (threadIdx.x == 0) a.kl_partials[blockIdx.x] = tot;
 }
+__global__ __launch_bounds__(256) void reparam_kernel(const ReparamArgs a) { reparam_body(a); }
+__global__ __launch_bounds__(256) void reparam_multi(const MultiSlot<ReparamArgs>* __restrict__ t) {
+    const MultiSlot<ReparamArgs>& s = t[blockIdx.z];
+    if (blockIdx.x >= s.gx) return;
+    reparam_body(s.a);
+}
+static MultiReg<ReparamArgs> reg_reparam(reparam_kernel, reparam_multi);
 
 int reparam_blocks(int rows, int Z) { return (int)(((long)rows * Z + 255) / 256); }
 
 void launch_reparam(hipStream_t s, const float* ML, long ldml, const float* eps_in, float* Zb, float* Eb, long ldz,
                     int rows, int Z, uint64_t seed, const DevState* st, long row0_global, float* kl_partials) {
-    SMRT_LAUNCH(reparam_kernel, dim3(reparam_blocks(rows, Z)), dim3(256), 0, s, ML, ldml, eps_in, Zb, Eb, ldz,
-                       rows, Z, seed, st, row0_global, kl_partials);
+    ReparamArgs a{ML, ldml, eps_in, Zb, Eb, ldz, rows, Z, seed, st, row0_global, kl_partials};
+    SMRT_LAUNCH(reparam_kernel, dim3(reparam_blocks(rows, Z)), dim3(256), 0, s, a);
 }
 
 // One thread per Philox block = FOUR consecutive normals of the stream (elements 4 q .. 4 q + 3): ten rounds and two
@@ -512,7 +516,7 @@ __device__ __forceinline__ float opt_update(const OptArgs& a, float w, float g, 
     }
 }
 
-__global__ __launch_bounds__(256) void optimizer_kernel(const OptArgs a) {
+__device__ __forceinline__ void optimizer_body(const OptArgs& a) {
     __shared__ float red[4];
     const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     float l2acc = 0.f;
@@ -584,6 +588,14 @@ __global__ __launch_bounds__(256) void optimizer_kernel(const OptArgs a) {
     if (threadIdx.x == 0) a.l2_partials[blockIdx.x] = tot;
 }
 
+__global__ __launch_bounds__(256) void optimizer_kernel(const OptArgs a) { optimizer_body(a); }
+__global__ __launch_bounds__(256) void optimizer_multi(const MultiSlot<OptArgs>* __restrict__ t) {
+    const MultiSlot<OptArgs>& s = t[blockIdx.z];
+    if (blockIdx.x >= s.gx) return;
+    optimizer_body(s.a);
+}
+static MultiReg<OptArgs> reg_optimizer(optimizer_kernel, optimizer_multi);
+
 int optimizer_blocks(long P) { return (int)((P / 4 + 255) / 256); }
 
 void launch_optimizer(hipStream_t s, const OptArgs& a, int* n_blocks_out) {
@@ -612,7 +624,7 @@ void launch_reduce_slabs(hipStream_t s, const float* G, int splits, long slab_st
 // =====================================================================================
 // Cost = mean(rec + kl) + l2 * sum 1/2 |W'|^2 ; advance the step-dependent scalars   autoencoder.py:479-480
 // =====================================================================================
-__global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
+__device__ __forceinline__ void finalize_body(const FinalizeArgs& a) {
     __shared__ float red[4];
     float s = 0.f;
     for (int i = threadIdx.x; i < a.n_bce; i += 256) s += a.bce[i];
@@ -634,6 +646,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) {
         }
     }
 }
+
+__global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) { finalize_body(a); }
+__global__ __launch_bounds__(256) void finalize_multi(const MultiSlot<FinalizeArgs>* __restrict__ t) {
+    const MultiSlot<FinalizeArgs>& s = t[blockIdx.z];
+    if (blockIdx.x >= s.gx) return;
+    finalize_body(s.a);
+}
+static MultiReg<FinalizeArgs> reg_finalize(finalize_kernel, finalize_multi);
 
 void launch_finalize(hipStream_t s, const FinalizeArgs& a) {
     SMRT_LAUNCH(finalize_kernel, dim3(1), dim3(256), 0, s, a);

@@ -4,8 +4,12 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
+#include <cstring>
+#include <functional>
 #include <tuple>
+#include <type_traits>
 #include <utility>
+#include <vector>
 
 namespace smrt {
 
@@ -48,9 +52,74 @@ inline void smrt_add_node(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_
     else if (g_build.err == hipSuccess) g_build.err = e;
 }
 
+// ---- grouped launches (api.hip: smrt_vae_train_epochs_multi).  Several independent handles that train the same kind of
+// net side by side -- the per-class VAEs of one smrt_balance call on one GPU -- go through the SAME kernel sequence, each
+// with grids far too small for the chip (4 to 120 workgroups).  While a host thread RECORDS, SMRT_LAUNCH stores the launch
+// instead of issuing it; the recorded sequences of all handles are then merged position by position, and launches of one
+// kernel become ONE launch of its grouped twin: gridDim.z = handle, the argument structs in a device table.
+template <class A> struct alignas(16) MultiSlot { A a; unsigned gx, gy, pad0, pad1; };   // + the handle's own grid extent
+
+struct RecordedLaunch {
+    const void* kernel = nullptr;           // the plain kernel
+    dim3 grid, block; unsigned shmem = 0;
+    std::vector<char> args;                 // bytes of its single argument struct (empty: has no grouped twin)
+    std::function<void(hipStream_t)> plain; // issues the launch as it was recorded
+};
+struct Recorder { std::vector<RecordedLaunch>* out = nullptr; };
+extern thread_local Recorder g_record;
+
+struct MultiInfo { const void* multi; size_t arg_size, slot_size, gx_off; };
+void smrt_register_multi(const void* kernel, const MultiInfo& info);
+const MultiInfo* smrt_multi_of(const void* kernel);
+template <class A> struct MultiReg {
+    MultiReg(void (*kernel)(A), void (*multi)(const MultiSlot<typename std::remove_const<A>::type>*)) {
+        using T = typename std::remove_const<A>::type;
+        smrt_register_multi((const void*)kernel, MultiInfo{(const void*)multi, sizeof(T), sizeof(MultiSlot<T>), offsetof(MultiSlot<T>, gx)});
+    }
+};
+
+// a launch outside recording: graph node while a graph is being built, plain launch otherwise
+template <class... KArgs>
+inline void smrt_issue(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t stream,
+                       std::tuple<KArgs...>& vals) {
+    void* ptrs[sizeof...(KArgs)];
+    smrt_arg_ptrs(vals, ptrs, std::index_sequence_for<KArgs...>{});
+    if (g_build.graph) {
+        hipKernelNodeParams kp{};
+        kp.func = (void*)kernel; kp.gridDim = grid; kp.blockDim = block; kp.sharedMemBytes = (unsigned)shmem;
+        kp.kernelParams = ptrs; kp.extra = nullptr;
+        hipGraphNode_t node = nullptr;
+        const hipError_t e = hipGraphAddKernelNode(&node, g_build.graph, g_build.prev ? &g_build.prev : nullptr,
+                                                   g_build.prev ? 1 : 0, &kp);
+        if (e == hipSuccess) { g_build.prev = node; ++g_build.nodes; }
+        else if (g_build.err == hipSuccess) g_build.err = e;
+    } else {
+        (void)hipLaunchKernel((const void*)kernel, grid, block, ptrs, shmem, stream);
+    }
+}
+template <class... KArgs, class... Args>
+inline void smrt_record(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t shmem, hipStream_t, Args&&... args) {
+    RecordedLaunch r;
+    r.kernel = (const void*)kernel; r.grid = grid; r.block = block; r.shmem = (unsigned)shmem;
+    std::tuple<typename std::remove_const<KArgs>::type...> vals(std::forward<Args>(args)...);
+    if constexpr (sizeof...(KArgs) == 1) {
+        using A = typename std::tuple_element<0, decltype(vals)>::type;
+        if (std::is_trivially_copyable<A>::value && smrt_multi_of((const void*)kernel)) {
+            r.args.resize(sizeof(A));
+            std::memcpy(r.args.data(), &std::get<0>(vals), sizeof(A));
+        }
+    }
+    r.plain = [kernel, grid, block, shmem, vals](hipStream_t s) mutable {
+        std::tuple<KArgs...> v2(vals);
+        smrt_issue(kernel, grid, block, shmem, s, v2);
+    };
+    g_record.out->push_back(std::move(r));
+}
+
 #define SMRT_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                   \
     do {                                                                                                      \
-        if (smrt::g_build.graph) smrt::smrt_add_node(kernel, grid, block, shmem, __VA_ARGS__);                \
+        if (smrt::g_record.out) smrt::smrt_record(kernel, grid, block, shmem, stream, __VA_ARGS__);           \
+        else if (smrt::g_build.graph) smrt::smrt_add_node(kernel, grid, block, shmem, __VA_ARGS__);           \
         else if (g_prof_start) hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, g_prof_start, g_prof_stop, 0, __VA_ARGS__); \
         else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                             \
     } while (0)
@@ -126,6 +195,15 @@ struct DropArgs {
     uint64_t seed;
     float keep;
     int injected;                    // masks already in `mask`
+};
+
+struct ReparamArgs {
+    const float* ML; long ldml;          // fused heads output [rows][ldml]: mu | log_sigma
+    const float* eps_in;                 // injected epsilon [rows][Z] contiguous, or null: the Philox stream
+    float* Zb; float* Eb; long ldz;      // z and the epsilon used, [rows][ldz]
+    int rows, Z;
+    uint64_t seed; const DevState* st; long row0_global;
+    float* kl_partials;                  // one partial KL sum per block
 };
 
 struct FinalizeArgs {

@@ -238,3 +238,35 @@ def test_diagnostic_peaks_are_sane():
     assert 0.5 < us < 100.0, us
     with pytest.raises(_hip.HipLibraryError):
         _hip.diag_step_floor(0, 0, 50, 8, 512)
+
+
+@pytest.mark.gpu
+def test_grouped_class_fits_are_bit_identical_to_separate_fits(monkeypatch):
+    """smrt_vae_train_epochs_multi: the per-class VAEs of one smrt_balance call trained side by side with grouped launches
+    (one launch per kernel for ALL classes) against the same call with every class fitted on its own.  Same kernels on the
+    same numbers: outputs, weights and epoch costs must agree bit for bit -- with classes of different sizes (different
+    numbers of mini-batches, ragged tails of 44, 2 and 13 rows), a net off the LDS-resident path, Adam."""
+    from smrt_amd.balance import smrt_balance
+    rs = np.random.RandomState(12)
+    D = 200
+    counts = {0: 900, 1: 300, 2: 130, 3: 77, 4: 64}
+    X = np.vstack([np.clip(rs.uniform(size=D) + 0.1 * rs.normal(size=(n, D)), 0, 1) for n in counts.values()])
+    y = np.concatenate([np.full(n, k) for k, n in counts.items()])
+    p = rs.permutation(len(y))
+    X, y = X[p], y[p]
+    kw = dict(n_hidden=300, n_latent_factors=7, balance_ratio=0.5, n_epochs=3, batch_size=64, random_state=3,
+              learning_function="adam", learning_rate=0.002, return_estimators=True)
+    monkeypatch.setenv("SMRT_CLASS_GROUP", "0")
+    Xs, ys, es = smrt_balance(X, y, **kw)
+    monkeypatch.setenv("SMRT_CLASS_GROUP", "1")
+    Xg, yg, eg = smrt_balance(X, y, **kw)
+    assert np.array_equal(Xs, Xg) and np.array_equal(ys, yg)
+    for label in (1, 2, 3, 4):
+        np.testing.assert_array_equal(es[label].sess.get_params(), eg[label].sess.get_params())
+        np.testing.assert_array_equal(es[label].epoch_costs_, eg[label].epoch_costs_)
+        assert eg[label].sess.step_count == es[label].sess.step_count == 3 * ((counts[label] + 63) // 64)
+    # grouped: one launch per kernel and step position for all four classes, not four
+    assert eg[1].sess.last_epoch_launches < 2 * es[1].sess.last_epoch_launches
+    o = OracleVAE(D, [300], 7, learning_function="adam", learning_rate=0.002, seed=3)
+    o.fit(X[y == 2], n_epochs=3, batch_size=64)
+    np.testing.assert_allclose(eg[2].epoch_costs_, np.array(o.epoch_costs_), rtol=1e-4)
