@@ -574,8 +574,32 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
 #endif
         n_bce = n_kl = (rows + 15) / 16;
     }
+    // The middle of the VAE at small mini-batches: heads + reparameterisation + first decoder layer in ONE launch forward,
+    // first decoder layer + latent + heads in ONE launch backward (small_gemm.hip: mid_fwd / mid_bwd; 2 Z <= 32).
+    static const bool mid_env = []() { const char* e = std::getenv("SMRT_HIP_MID"); return e ? std::atoi(e) != 0 : true; }();
+    const bool mid = mid_env && !fused_step && !h->ae && rows <= SMALL_M_MAX && 2 * Z <= 32 && L >= 1;
+    MidArgs ma{};
+    if (mid) {
+        const LayerI& yh = h->lay[HL];
+        const LayerI& yd = h->lay[HL + 1];
+        ma.H = in_of(HL); ma.ldh = ldin_of(HL);
+        ma.Wh = Wuse + yh.off; ma.ldwh = yh.ld; ma.bh = h->W + yh.off + (long)yh.fi * yh.ld;
+        ma.Wd = Wuse + yd.off; ma.ldwd = yd.ld; ma.bd = h->W + yd.off + (long)yd.fi * yd.ld;
+        ma.ML = h->out[HL]; ma.ldml = yh.ld;
+        ma.Zb = h->Zb; ma.Eb = h->Eb; ma.ldz = rup4(Z);
+        ma.OUT = h->out[HL + 1]; ma.ldo = yd.ld;
+        ma.eps_in = eps_in; ma.kl_partials = h->kl_p;
+        ma.DP = h->dpre[HL + 1]; ma.lddp = yd.ld;
+        ma.DML = h->dpre[HL]; ma.lddml = yh.ld;
+        ma.DOUT = h->dpre[HL - 1]; ma.lddo = h->lay[HL - 1].ld;
+        ma.M = rows; ma.hL = yh.fi; ma.Z = Z; ma.act = yh.act; ma.inv_batch = inv_batch;
+        ma.seed = h->cfg.seed; ma.st = h->st; ma.row0_global = row0_global;
+        n_kl = mid_row_blocks(rows);
+    }
     // ---- forward
     for (int l = 0; l < NL && !fused_step; ++l) {
+        if (mid && l == HL) { ProfScope ps(h, PK_FWD); launch_mid_fwd(s, ma); ++launches; continue; }
+        if (mid && l == HL + 1) continue;
         const LayerI& y = h->lay[l];
         GemmArgs a{};
         a.A = in_of(l); a.lda = ldin_of(l);
@@ -617,6 +641,8 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
     }
     // ---- backward through the activations
     for (int l = NL - 1; l >= 1 && !fused_step; --l) {
+        if (mid && l == HL + 1) { ProfScope ps(h, PK_BWD_LATENT); launch_mid_bwd(s, ma); ++launches; continue; }
+        if (mid && l == HL) continue;
         const LayerI& y = h->lay[l];
         GemmArgs a{};
         a.A = h->dpre[l]; a.lda = y.ld; a.M = rows; a.K = y.fo;

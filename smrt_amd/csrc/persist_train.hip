@@ -1,7 +1,7 @@
 // Persistent training kernel for nets that fit in LDS: ONE launch runs every mini-batch of an epoch
 // (smrt/autoencode/base.py:202-217, the `for batch in batches` loop and everything inside its sess.run).
 //
-// Grid: G = ceil(batch_size / 16) COMPUTE workgroups + ceil(tiles / 8) OWNER workgroups, 8 waves each, one per CU, all
+// Grid: G = ceil(batch_size / 16) COMPUTE workgroups + ceil(tiles / 4) OWNER workgroups, 8 waves each, one per CU, all
 // resident for the whole launch.
 //   compute workgroup b carries rows [16 b, 16 b + 16) of every mini-batch through all forward / backward stages with the
 //            WEIGHTS RESIDENT IN LDS (the same stage body as the per-launch kernel, fused_stage.hpp); every layer output

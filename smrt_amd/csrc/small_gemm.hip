@@ -266,6 +266,176 @@ void launch_small_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a) {
     }
 }
 
+// ------------------------------------------------------------------ the middle of the VAE, fused
+// At these sizes every launch costs ~4.5 us before it computes anything (its arguments, its operands and the step scalars
+// are three dependent memory round trips: the bare reparameterisation, 1 280 elements, takes 4.5 us), and the three
+// launches around the latent layer -- heads (2 Z <= 32 columns: four workgroups), reparameterisation, first decoder layer
+// (K = Z) -- are nothing but that floor, three times: 20 us of a 73 us step of the reference's own net at batch 128.
+// Here every workgroup of the first decoder layer's grid recomputes the heads tile of its 32 rows (one 32x32 tile over
+// K = h_L: what any workgroup of the neighbouring layers does), reparameterises into LDS, and multiplies its own 32
+// output columns from there; the workgroups of the first column also write the heads, z, epsilon and the KL partial.
+// Backward the same way: dz tile (K = h_L) -> latent gradients in LDS -> own 32 columns of the encoder's dPre (K = 2 Z).
+// Same arithmetic in the same order as the separate kernels (small_tile, the same epilogues): results are bit-identical.
+constexpr int MID_LD = 36;             // LDS row stride of the 32-row latent tiles (2 Z <= 32 columns + slack for clamped reads)
+
+__device__ __forceinline__ void mid_fwd_body(const MidArgs& a) {
+    __shared__ float red[4 * ST * SRED];
+    __shared__ __align__(16) float ml[ST * MID_LD];
+    __shared__ __align__(16) float zt[ST * MID_LD];
+    __shared__ float sred[4];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.y * ST, n0 = blockIdx.x * ST;
+    const int lr = tid >> 3, c4 = (tid & 7) * 4, row = m0 + lr;
+    const int Z = a.Z, N2 = 2 * a.Z;
+    const bool first = blockIdx.x == 0;
+    float pb[4], pd[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        pb[c] = a.bh[min(c4 + c, N2 - 1)];
+        pd[c] = a.bd[min(n0 + c4 + c, a.hL - 1)];
+    }
+    // epsilon of this thread's reparameterisation elements, requested now (injected) -- up to 2 per thread (32 Z <= 512)
+    float pe[2] = {0.f, 0.f};
+    if (a.eps_in) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + u * 256;
+            const int r = i / Z, k = i - r * Z;
+            if (i < ST * Z) pe[u] = a.eps_in[(long)min(m0 + r, a.M - 1) * Z + k];
+        }
+    }
+    const uint32_t step = a.st->step;
+    // ---- heads: act(h . [W_mu | W_ls] + b)                                        layer.py:312-317
+    const f32x4v v = small_tile<INNER, OUTER, false>(a.H, a.ldh, a.M, a.Wh, a.ldwh, N2, m0, 0, a.hL, red);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = c4 + c;
+        const bool in = row < a.M && col < N2;
+        const float y = in ? act_fwd(a.act, v[c] + pb[c]) : 0.f;
+        ml[lr * MID_LD + col] = y;
+        if (first && in) a.ML[(long)row * a.ldml + col] = y;
+    }
+    __syncthreads();
+    // ---- z = mu + eps * exp(log_sigma), KL row terms                              layer.py:279, _ae_utils.py:49
+    float kl = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * 256;
+        if (i < ST * Z) {
+            const int r = i / Z, k = i - r * Z, grow = m0 + r;
+            float z = 0.f;
+            if (grow < a.M) {
+                const float mu = ml[r * MID_LD + k], ls = ml[r * MID_LD + Z + k];
+                const float e = a.eps_in ? pe[u] : philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + grow) * Z + k);
+                z = mu + e * expf(ls);
+                if (first) {
+                    a.Zb[(long)grow * a.ldz + k] = z;
+                    a.Eb[(long)grow * a.ldz + k] = e;
+                    kl += -0.5f * (1.0f + 2.0f * ls - mu * mu - expf(2.0f * ls));
+                }
+            }
+            zt[r * MID_LD + k] = z;
+        }
+    }
+    if (first) {                                        // (block-uniform)
+        const float tot = block_sum_256(kl, sred);
+        if (tid == 0) a.kl_partials[blockIdx.y] = tot;
+    }
+    __syncthreads();
+    // ---- first decoder layer, this workgroup's 32 columns: act(z . W + b), z from LDS (K = Z)        layer.py:325-331
+    const f32x4v v2 = small_tile<INNER, OUTER, false>(zt, MID_LD, ST, a.Wd, a.ldwd, a.hL, 0, n0, Z, red);
+    if (row < a.M) {
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = act_fwd(a.act, v2[c] + pd[c]);
+        float* dst = a.OUT + (long)row * a.ldo + n0 + c4;
+        if (n0 + c4 + 3 < a.hL && (a.ldo & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (n0 + c4 + c < a.hL) dst[c] = o[c];
+        }
+    }
+}
+
+__device__ __forceinline__ void mid_bwd_body(const MidArgs& a) {
+    __shared__ float red[4 * ST * SRED];
+    __shared__ __align__(16) float dh[ST * MID_LD];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.y * ST, n0 = blockIdx.x * ST;
+    const int lr = tid >> 3, c4 = (tid & 7) * 4, row = m0 + lr;
+    const int Z = a.Z, N2 = 2 * a.Z;
+    const bool first = blockIdx.x == 0;
+    const int rowc = min(row, a.M - 1);
+    float pmu[4], pls[4], pe[4], py[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int kc = min(c4 + c, Z - 1);
+        pmu[c] = a.ML[(long)rowc * a.ldml + kc];
+        pls[c] = a.ML[(long)rowc * a.ldml + Z + kc];
+        pe[c] = a.Eb[(long)rowc * a.ldz + kc];
+        py[c] = a.H[(long)rowc * a.ldh + min(n0 + c4 + c, a.hL - 1)];
+    }
+    // ---- dz = dPre_dec1 . W_dec1^T (K = h_L), then through the reparameterisation and the KL term into both heads
+    //      dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B              layer.py:279, _ae_utils.py:49
+    const f32x4v v = small_tile<INNER, INNER, false>(a.DP, a.lddp, a.M, a.Wd, a.ldwd, Z, m0, 0, a.hL, red);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = c4 + c;
+        if (col < Z) {
+            float g_mu = 0.f, g_ls = 0.f;
+            if (row < a.M) {
+                const float mu = pmu[c], ls = pls[c], e = pe[c];
+                const float el = expf(ls);
+                g_mu = act_bwd(a.act, mu, v[c] + mu * a.inv_batch);
+                g_ls = act_bwd(a.act, ls, v[c] * e * el + (expf(2.0f * ls) - 1.0f) * a.inv_batch);
+                if (first) {
+                    a.DML[(long)row * a.lddml + col] = g_mu;
+                    a.DML[(long)row * a.lddml + Z + col] = g_ls;
+                }
+            }
+            dh[lr * MID_LD + col] = g_mu;
+            dh[lr * MID_LD + Z + col] = g_ls;
+        }
+    }
+    __syncthreads();
+    // ---- dPre of the last encoder layer, this workgroup's 32 columns: (dPre_heads . W_heads^T) * act'(h)   (K = 2 Z)
+    const f32x4v v2 = small_tile<INNER, INNER, false>(dh, MID_LD, ST, a.Wh, a.ldwh, a.hL, 0, n0, N2, red);
+    if (row < a.M) {
+        float o[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = act_bwd(a.act, py[c], v2[c]);
+        float* dst = a.DOUT + (long)row * a.lddo + n0 + c4;
+        if (n0 + c4 + 3 < a.hL && (a.lddo & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (n0 + c4 + c < a.hL) dst[c] = o[c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void mid_fwd_kernel(const MidArgs a) { mid_fwd_body(a); }
+__global__ __launch_bounds__(256, 2) void mid_bwd_kernel(const MidArgs a) { mid_bwd_body(a); }
+__global__ __launch_bounds__(256, 2) void mid_fwd_multi(const MultiSlot<MidArgs>* __restrict__ t) {
+    const MultiSlot<MidArgs>& s = t[blockIdx.z];
+    if (blockIdx.x >= s.gx || blockIdx.y >= s.gy) return;
+    mid_fwd_body(s.a);
+}
+__global__ __launch_bounds__(256, 2) void mid_bwd_multi(const MultiSlot<MidArgs>* __restrict__ t) {
+    const MultiSlot<MidArgs>& s = t[blockIdx.z];
+    if (blockIdx.x >= s.gx || blockIdx.y >= s.gy) return;
+    mid_bwd_body(s.a);
+}
+static MultiReg<MidArgs> reg_mid_fwd(mid_fwd_kernel, mid_fwd_multi);
+static MultiReg<MidArgs> reg_mid_bwd(mid_bwd_kernel, mid_bwd_multi);
+
+int mid_row_blocks(int rows) { return (rows + ST - 1) / ST; }
+void launch_mid_fwd(hipStream_t s, const MidArgs& a) {
+    SMRT_LAUNCH(mid_fwd_kernel, dim3((a.hL + ST - 1) / ST, (a.M + ST - 1) / ST), dim3(256), 0, s, a);
+}
+void launch_mid_bwd(hipStream_t s, const MidArgs& a) {
+    SMRT_LAUNCH(mid_bwd_kernel, dim3((a.hL + ST - 1) / ST, (a.M + ST - 1) / ST), dim3(256), 0, s, a);
+}
+
 // ------------------------------------------------------------------ weight + bias gradients of every layer, one launch
 // [X | 1]^T . dPre with K = rows of the mini-batch (no split-K: one slab); the virtual ones index gives the bias row.
 __device__ __forceinline__ void small_dw_body(const DwArgs& a) {

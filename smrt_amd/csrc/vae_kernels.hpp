@@ -206,6 +206,28 @@ struct ReparamArgs {
     float* kl_partials;                  // one partial KL sum per block
 };
 
+// The middle of the VAE at small mini-batches (small_gemm.hip): heads -> reparameterisation -> first decoder layer in one
+// launch forward, first decoder layer -> latent -> heads in one launch backward (2 Z <= 32).
+struct MidArgs {
+    const float* H; long ldh;                        // output of the last encoder layer [M][ldh]
+    const float* Wh; long ldwh; const float* bh;     // fused heads [hL][ldwh] (mu | log_sigma columns), bias [2Z]
+    const float* Wd; long ldwd; const float* bd;     // first decoder layer [Z][ldwd], bias [hL]
+    float* ML; long ldml;                            // heads output [M][ldml]
+    float* Zb; float* Eb; long ldz;                  // z and the epsilon used [M][ldz]
+    float* OUT; long ldo;                            // forward: first decoder layer's output [M][ldo]
+    const float* eps_in;                             // injected epsilon [M][Z] contiguous, or null: the Philox stream
+    float* kl_partials;                              // one partial KL sum per 32-row block
+    const float* DP; long lddp;                      // backward: dPre of the first decoder layer [M][lddp]
+    float* DML; long lddml;                          // dPre of the heads [M][lddml]
+    float* DOUT; long lddo;                          // dPre of the last encoder layer [M][lddo]
+    int M, hL, Z, act;
+    float inv_batch;
+    uint64_t seed; const DevState* st; long row0_global;
+};
+void launch_mid_fwd(hipStream_t s, const MidArgs& a);
+void launch_mid_bwd(hipStream_t s, const MidArgs& a);
+int  mid_row_blocks(int rows);
+
 struct FinalizeArgs {
     const float* bce; int n_bce;
     const float* kl;  int n_kl;
