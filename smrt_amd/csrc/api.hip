@@ -106,7 +106,7 @@ struct smrt_vae {
     DwTile* tile_tab = nullptr;      // per-tile records of the fused dW + optimizer kernel
     // persistent whole-epoch kernel (persist_train.hip)
     bool persist_ok = false;         // the net qualifies (fits in LDS, no dropout, VAE)
-    unsigned* pcnt = nullptr;        // counters + error word (64 words)
+    unsigned* pcnt = nullptr;        // producer flags + error word (256 words)
     int persist_wgs_held = 0;        // workgroups reserved in the process-wide budget while a call runs
 
     // per-kernel profiling (eager launches bracketed by events)
@@ -471,7 +471,7 @@ static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_r
     a.lr = h->cfg.learning_rate; a.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
     a.gmin = h->cfg.gclip_min; a.gmax = h->cfg.gclip_max;
     // counters and the error word start at zero for every launch (stream-ordered, no host wait)
-    if (hipMemsetAsync(h->pcnt, 0, 64 * sizeof(unsigned), s) != hipSuccess) return -1;
+    if (hipMemsetAsync(h->pcnt, 0, 256 * sizeof(unsigned), s) != hipSuccess) return -1;
 #ifdef SMRT_STAMPS
     static unsigned long long* pdbg = nullptr;
     if (!pdbg) { (void)hipMalloc((void**)&pdbg, 64 * 8); (void)hipMemset(pdbg, 0, 64 * 8); }
@@ -801,7 +801,7 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
             carve(a, &h->Wimg, h->fused ? (size_t)h->fplan.img_total + 16 : 0);
             carve(a, &h->st, (size_t)1);
             carve(a, &h->ticket, (size_t)4);
-            carve(a, &h->pcnt, (size_t)64);
+            carve(a, &h->pcnt, (size_t)256);
             carve(a, &h->cost_dev, (size_t)4);
             carve(a, &h->l2_p, (size_t)std::max(h->n_l2, dw_opt_blocks(h->tiles16)));      // (>= persist_owner_workgroups)
             carve(a, &h->stage_tab, h->fused ? (size_t)h->P_int / 4 : 0);
@@ -993,6 +993,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     // The persistent whole-epoch kernel when the net and the schedule qualify and its workgroups fit the process-wide
     // budget of co-resident persistent workgroups (released when this call returns, whichever way).
     int PG = persist_grid(h, bmax);
+    if (PG && persist_owner_workgroups(h->tiles16) > persist_max_owner_workgroups()) PG = 0;
     const int PW = PG ? PG + persist_owner_workgroups(h->tiles16) : 0;          // workgroups of the launch
     if (PG) {
         const int prev = g_persist_wgs.fetch_add(PW);
@@ -1002,7 +1003,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     auto persist_failed = [&]() -> bool {
         if (!PG) return false;
         unsigned e = 0;
-        if (hipMemcpy(&e, h->pcnt + 32, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return true;
+        if (hipMemcpy(&e, h->pcnt + 192, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return true;
         return e != 0;
     };
 

@@ -14,13 +14,14 @@
 // (A first version let the compute workgroups reduce 16-row partial tiles themselves; in-kernel stamps showed 4.6 us of
 // tile work and 2.9 us of owner work per step on the compute workgroups' own critical path -- 22.6 us a step against the
 // two-kernel step's 19.5.  Owners on CUs of their own take all of it off that path.)
-// Two monotonic counters order the phases (cdna guide, Guideline 16, the counter form; MI355X_MICROARCH "Valid forms",
-// first table row): every byte that crosses is stored `sc1` (write-through), each storing wave drains its stores
-// (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane adds to the counter at agent scope; the consumer polls
-// the counter from one lane with an `sc1` load, the workgroup meets at a barrier, and EVERY load of crossed bytes is an
-// `sc1` buffer load into registers.  No dispatch order, timing or XCD placement is assumed.  Every spin is bounded
+// One monotonic flag per producer workgroup orders the phases (cdna guide, Guideline 16, the flag form, sharded by
+// producer; MI355X_MICROARCH "Valid forms", first table row): every byte that crosses is stored `sc1` (write-through),
+// each storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane stores the step
+// number into the workgroup's flag with an agent-scope `sc1` store; the consumer's first wave polls EVERY producer's flag
+// with `sc1` loads, the workgroup meets at a barrier, and EVERY load of crossed bytes is an `sc1` buffer load into
+// registers.  No dispatch order, timing or XCD placement is assumed.  Every spin is bounded
 // (2 s of wall clock): on a time-out the workgroup raises an error word that all others poll, and every wave leaves.
-// Counters and the error word are zeroed by a hipMemsetAsync in front of every launch.
+// Flags and the error word are zeroed by a hipMemsetAsync in front of every launch.
 //
 // Reference arithmetic: smrt/autoencode/layer.py:272-279,299-340,365-368; _ae_utils.py:15-49; base.py:127-149,198-222.
 #include "fused_stage.hpp"
@@ -48,19 +49,27 @@ __device__ __forceinline__ void store4_sc1(float* p, float v) {        // global
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// One lane waits until *cnt >= target (monotonic counter).  false: gave up (time-out here, or another workgroup's).
-// ONE relaxed sc1 load per round trip with a short sleep between: keeping four polls in flight instead (to see a change a
-// quarter round trip earlier) made the epoch 3 % SLOWER -- 36 pollers then load the same two lines back to back.
-__device__ __forceinline__ bool wait_count(unsigned* cnt, unsigned target, unsigned* err) {
+// Wave 0 waits until every one of the n flags has reached `target` (each flag is written by ONE producer workgroup and
+// only grows).  Lane i polls flags i, i + 64, ...: one relaxed sc1 load per lane and round trip, a short sleep between.
+// false: gave up (time-out here, or another workgroup's).  A single counter that every producer adds to cost more: the
+// adds of one step serialise on their line in L2 (11-13 ns each, 28 owners) and the add is a round trip where the flag is
+// a fire-and-forget store.  (Keeping four polls in flight to see a change a quarter round trip earlier was 3 % SLOWER.)
+constexpr int PCNT_FG = 0, PCNT_FW = 64, PCNT_ERR = 192;      // word offsets in PersistArgs::cnt (256 words, zeroed per launch)
+constexpr int PCNT_FW_MAX = 128;
+__device__ __forceinline__ bool wait_flags(unsigned* f, int n, unsigned target, unsigned* err, int lane) {
     const unsigned long long t0 = wall_clock64();                    // 100 MHz
     for (unsigned spins = 0;; ++spins) {
-        const unsigned v = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)(v - target) >= 0) return true;
+        bool behind = false;
+        for (int i = lane; i < n; i += 64) {
+            const unsigned v = __hip_atomic_load(f + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            behind |= (int)(v - target) < 0;
+        }
+        if (__builtin_amdgcn_ballot_w64(behind) == 0ull) return true;
         __builtin_amdgcn_s_sleep(1);
         if ((spins & 63u) == 63u) {
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
             if (wall_clock64() - t0 > 200000000ull) {                // 2 s: a peer is not resident or has died
-                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
         }
@@ -90,9 +99,9 @@ __device__ __forceinline__ void owner_role(const PersistArgs& a, int* go_flag, f
     const int t = ow * OWNER_TILES + wave;
     const bool live = wave < OWNER_TILES && t < a.total_tiles;      // (idle waves shadow the last tile and store nothing)
     const DwTile T = a.tiles[live ? t : a.total_tiles - 1];
-    unsigned* const cnt_g = a.cnt;
-    unsigned* const cnt_w = a.cnt + 16;
-    unsigned* const err = a.cnt + 32;
+    unsigned* const flag_g = a.cnt + PCNT_FG;
+    unsigned* const flag_w = a.cnt + PCNT_FW;
+    unsigned* const err = a.cnt + PCNT_ERR;
     const int m0 = T.m0, n0 = T.n0, fi = T.fi, fo = T.fo;
     const int col = n0 + c, row0 = m0 + 4 * q;
     float w[4], s0[4], s1[4];
@@ -122,7 +131,10 @@ __device__ __forceinline__ void owner_role(const PersistArgs& a, int* go_flag, f
         const int n_active = (rows + FTM - 1) / FTM;
         const bool last = step == a.n_steps - 1;
         OST(45);
-        if (tid == 0) *go_flag = wait_count(cnt_g, (unsigned)G * (unsigned)(step + 1), err) ? 1 : 0;
+        if (wave == 0) {
+            const bool go = wait_flags(flag_g, G, (unsigned)(step + 1), err, lane);
+            if (lane == 0) *go_flag = go ? 1 : 0;
+        }
         __syncthreads();
         if (!*go_flag) return;
         OST(46);
@@ -194,7 +206,7 @@ __device__ __forceinline__ void owner_role(const PersistArgs& a, int* go_flag, f
         __syncthreads();
         OST(48);
         if (tid == 0) {
-            __hip_atomic_fetch_add(cnt_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flag_w + ow, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (last) {
                 float s = 0.f;
 #pragma unroll
@@ -224,10 +236,10 @@ __global__ __launch_bounds__(FTHREADS) void persist_train_kernel(const PersistAr
     if (wg >= G) { owner_role(a, &go_flag, red); return; }
 
     const int Z = a.Z;
-    unsigned* const cnt_g = a.cnt;                 // activations / gradients published  (one add per compute workgroup and step)
-    unsigned* const cnt_w = a.cnt + 16;            // new weights published              (one add per owner workgroup and step)
-    unsigned* const err = a.cnt + 32;
-    const unsigned n_owner = (unsigned)(gridDim.x - G);
+    unsigned* const flag_g = a.cnt + PCNT_FG;      // activations / gradients published: flag b = steps done by compute workgroup b
+    unsigned* const flag_w = a.cnt + PCNT_FW;      // new weights published:             flag o = steps done by owner workgroup o
+    unsigned* const err = a.cnt + PCNT_ERR;
+    const int n_owner = (int)gridDim.x - G;
     const __amdgpu_buffer_rsrc_t r_img = make_rsrc(a.Wimg, (unsigned)(a.img_total * 4));
 
     // ---- launch prologue: stage records, zeroed activation tiles
@@ -282,7 +294,10 @@ __global__ __launch_bounds__(FTHREADS) void persist_train_kernel(const PersistAr
         PST(0);
         // ---- L-phase: the weights of this step into LDS.  Step 0 reads what the host (or the previous launch) left in
         // the image twin; later steps wait until every owner workgroup has published its tiles of the previous step.
-        if (tid == 0) go_flag = (step == 0) ? 1 : (wait_count(cnt_w, n_owner * (unsigned)step, err) ? 1 : 0);
+        if (wave == 0) {
+            const bool go = step == 0 || wait_flags(flag_w, n_owner, (unsigned)step, err, lane);
+            if (lane == 0) go_flag = go ? 1 : 0;
+        }
         __syncthreads();
         if (!go_flag) return;
         PST(1);
@@ -368,14 +383,17 @@ __global__ __launch_bounds__(FTHREADS) void persist_train_kernel(const PersistAr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         PST(41);
-        if (tid == 0) __hip_atomic_fetch_add(cnt_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(flag_g + wg, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         draw_eps(step + 1);          // the epsilon tile is free (the stages are done): next step's draw hides behind the owners
     }
 
     // ---- launch epilogue: workgroup 0 advances the step scalars (every workgroup read them in its prologue, before the
     // first counter add; this store comes after the last counter wait)
     if (wg == 0) {
-        if (tid == 0) go_flag = wait_count(cnt_w, n_owner * (unsigned)a.n_steps, err) ? 1 : 0;
+        if (wave == 0) {
+            const bool go = wait_flags(flag_w, n_owner, (unsigned)a.n_steps, err, lane);
+            if (lane == 0) go_flag = go ? 1 : 0;
+        }
         __syncthreads();
         if (go_flag && tid == 0) {
             float p1 = a.st->b1pow, p2 = a.st->b2pow;
@@ -396,5 +414,6 @@ int persist_set_max_lds(int bytes) {
 }
 
 int persist_owner_workgroups(int total_tiles) { return (total_tiles + OWNER_TILES - 1) / OWNER_TILES; }
+int persist_max_owner_workgroups() { return PCNT_FW_MAX; }
 
 }  // namespace smrt

@@ -333,6 +333,7 @@ struct PersistArgs {
 void launch_persist_train(hipStream_t s, const PersistArgs& a, int n_workgroups);
 int  persist_set_max_lds(int bytes);
 int  persist_owner_workgroups(int total_tiles);     // one owner wave per 16x16 weight-gradient tile, 4 per workgroup
+int  persist_max_owner_workgroups();               // one flag word per owner workgroup
 
 // Fused inference (encode / decode / generate) for nets whose weights fit in LDS: fused_small.hip
 struct InferStage { int K16, N, N16, w_off, nn, b_off, act, pad; };   // image offsets relative to the staged range
