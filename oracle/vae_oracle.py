@@ -162,7 +162,9 @@ def _box_muller_f32(xa, xb):
     u1 = ((xa >> np.uint32(8)).astype(f) + f(1.0)) * f(2.0 ** -24)        # (0, 1]
     u2 = (xb >> np.uint32(8)).astype(f) * f(2.0 ** -24)                   # [0, 1)
     r = np.sqrt(f(-2.0) * np.log(u1)).astype(f)
-    th = (f(6.283185307179586) * u2).astype(f)
+    # the angle 2 pi u2 in fp64, cos / sin rounded to fp32 once: the kernel reduces the quadrant exactly (in revolutions)
+    # and evaluates a ~1 ulp polynomial, so both sides are within an ulp or two of the exact value
+    th = 6.283185307179586 * u2.astype(np.float64)
     return (r * np.cos(th).astype(f)).astype(f), (r * np.sin(th).astype(f)).astype(f)
 
 

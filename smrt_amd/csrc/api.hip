@@ -1371,7 +1371,8 @@ struct GenDraw { uint64_t elem0; float loc, scale; };
 static int infer_fused(smrt_vae* h, int l0, int l1, const float* in, long ldin, long n,
                        float* out0, long ld0, int split, float* out1, long ld1, const GenDraw* gen = nullptr) {
     if (!h->fused || !h->Wimg || n <= 0) return 0;
-    if (!in && !(gen && (h->flay[l0].fi & 3) == 0 && (gen->elem0 & 3) == 0)) return 0;   // in-kernel draw: whole Philox blocks only
+    // in-kernel draw: whole Philox blocks only, at most two k-blocks of latent factors
+    if (!in && !(gen && (h->flay[l0].fi & 3) == 0 && h->flay[l0].fi <= 32 && (gen->elem0 & 3) == 0)) return 0;
     const char* e = std::getenv("SMRT_HIP_FUSED_INFER");
     if (e && std::atoi(e) == 0) return 0;
     InferArgs a{};
@@ -1393,6 +1394,7 @@ static int infer_fused(smrt_vae* h, int l0, int l1, const float* in, long ldin, 
     if (!in) { a.gen_seed = h->cfg.seed; a.gen_elem0 = gen->elem0; a.gen_loc = gen->loc; a.gen_scale = gen->scale; }
     a.out0 = out0; a.ld0 = ld0; a.split = split; a.out1 = out1; a.ld1 = ld1;
     const int N = h->flay[l1].fo;
+    a.vec_in = (in && a.K % 4 == 0 && ldin % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 1 : 0;
     a.vec_out = (split >= N && N % 4 == 0 && ld0 % 4 == 0 && ((uintptr_t)out0 & 15) == 0) ? 1 : 0;
     // the image twin must hold W itself: under dropout it follows the post-dropout weights of the last step
     // (inference runs with keep = 1, autoencoder.py:448) and training rebuilds it every step anyway
@@ -1403,7 +1405,31 @@ static int infer_fused(smrt_vae* h, int l0, int l1, const float* in, long ldin, 
         launch_build_image(h->stream, h->W, h->stage_tab, h->Wimg, (int)(h->P_int / 4));
         h->img_valid = true;
     }
+#ifdef SMRT_STAMPS
+    static unsigned long long* idbg = nullptr;
+    if (!idbg) { (void)hipMalloc((void**)&idbg, 64 * 8); (void)hipMemset(idbg, 0, 64 * 8); }
+    a.dbg = idbg;
+#endif
     if (launch_fused_infer(h->stream, a) != 0) return 0;
+#ifdef SMRT_STAMPS
+    {   // diagnostic build: wave 0 of workgroup 0, its third block of rows (wall_clock64 = 100 MHz; clock64 = shader clock)
+        (void)hipStreamSynchronize(h->stream);
+        unsigned long long hb[64];
+        (void)hipMemcpy(hb, idbg, 64 * 8, hipMemcpyDeviceToHost);
+        static int once = 0;
+        if (once++ < 2 && n > 100000) {
+            const int ids[] = {0, 1, 2, 3, 4, 5, 6, 10, 11};
+            int prev = 0;
+            for (int k = 1; k < 9; ++k) {
+                const int i = ids[k];
+                if (!hb[i]) continue;
+                fprintf(stderr, "infer stamp %d: +%.2f us  (%.0f shader cycles)\n", i, (double)(hb[i] - hb[prev]) * 0.01,
+                        (double)(hb[32 + i] - hb[32 + prev]));
+                prev = i;
+            }
+        }
+    }
+#endif
     return 1;
 }
 

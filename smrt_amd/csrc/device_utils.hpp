@@ -102,14 +102,43 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
     return Philox4{c0, c1, c2, c3};
 }
 
+// sin and cos of 2 pi u for u = k / 2^24 in [0, 1).  In revolutions the quadrant reduction is EXACT (4 u - rint(4 u) has no
+// rounding), which leaves one rounding in the angle and the two cephes minimax polynomials on [-pi/4, pi/4]: ~1 ulp, about
+// 25 VALU instructions for the pair against ~150 for libm's sinf + cosf with their general range reduction.
+// Every operation is spelled out (fmaf / fmul_rn): the same bits wherever this is inlined, whatever the compiler would have
+// contracted there.
+__device__ __forceinline__ void sincos_rev(float u, float& s, float& c) {
+    const float x = 4.0f * u;
+    const float qf = rintf(x);                                        // 0 .. 4
+    const float a = __fmul_rn(x - qf, 1.5707963267948966f);           // [-pi/4, pi/4]
+    const float a2 = __fmul_rn(a, a);
+    float sp = -1.9515295891e-4f;
+    sp = __fmaf_rn(sp, a2, 8.3321608736e-3f);
+    sp = __fmaf_rn(sp, a2, -1.6666654611e-1f);
+    const float sn = __fmaf_rn(__fmul_rn(a, a2), sp, a);
+    float cp = 2.443315711809948e-5f;
+    cp = __fmaf_rn(cp, a2, -1.388731625493765e-3f);
+    cp = __fmaf_rn(cp, a2, 4.166664568298827e-2f);
+    const float cs = __fmaf_rn(__fmul_rn(a2, a2), cp, __fmaf_rn(-0.5f, a2, 1.0f));
+    const int qi = (int)qf & 3;                                       // angle = qi * pi/2 + a
+    s = (qi & 1) ? cs : sn;
+    c = (qi & 1) ? sn : cs;
+    if (qi == 1 || qi == 2) c = -c;
+    if (qi >= 2) s = -s;
+}
+
 __device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float& n0, float& n1) {
     const float u1 = ((float)(xa >> 8) + 1.0f) * 5.9604644775390625e-08f;   // (0,1], exact in fp32
     const float u2 = (float)(xb >> 8) * 5.9604644775390625e-08f;            // [0,1)
-    const float r = sqrtf(-2.0f * logf(u1));
-    const float th = 6.283185307179586f * u2;
-    n0 = r * cosf(th);
-    n1 = r * sinf(th);
+    const float r = __builtin_amdgcn_sqrtf(__fmul_rn(-2.0f, logf(u1)));     // v_sqrt_f32: 1 ulp
+    float sn, cs;
+    sincos_rev(u2, sn, cs);
+    n0 = __fmul_rn(r, cs);
+    n1 = __fmul_rn(r, sn);
 }
+
+// loc + scale * n of a drawn normal, the same bits in every kernel that applies it
+__device__ __forceinline__ float shift_scale(float loc, float scale, float n) { return __fmaf_rn(scale, n, loc); }
 
 // Standard normal for flat element index e of (stream, step).
 __device__ __forceinline__ float philox_normal1(uint64_t seed, uint32_t stream, uint32_t step, uint64_t e) {

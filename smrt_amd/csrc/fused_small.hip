@@ -429,15 +429,19 @@ void launch_build_image(hipStream_t s, const float* Wflat, const int* tab, float
 // the fused path keep the per-layer chain.
 // =====================================================================================
 constexpr int IMAXT = 8;               // activations up to 128 wide
-constexpr int ITHREADS = 512;          // 8 waves in ONE workgroup per CU (2 per SIMD, up to 256 VGPRs each).  Several smaller workgroups per CU
-                                       // were slower: a persistent grid is not spread evenly over the CUs by the dispatcher
+// ONE workgroup per CU (several smaller ones were slower: a persistent grid is not spread evenly over the CUs by the
+// dispatcher) of 16 waves = 4 per SIMD at 128 VGPRs: a wave's chain draw -> layer -> activation -> layer -> store is serial,
+// so what keeps the matrix pipe fed is the OTHER waves of the SIMD (2 per SIMD: C2's generate 0.086 ms, 3: 0.081, 4: 0.078).
+// The 8-wave variant remains for chains whose wave-private I/O tiles (ragged rows only) would not fit in LDS 16 times.
 
+// (omode: 0 = the outputs become the next layer's fragments; 1 = last layer into the wave's LDS tile; 2 = last layer
+// straight to global memory, 16 bytes per lane and tile: every row gets 64 contiguous bytes per store instruction.)
 // One layer for one wave, all NN output tiles at once: acc[t] starts at the bias, and for every 16-wide k-block the NN
 // weight fragments are requested in one batch and multiplied into NN independent accumulators (consecutive MFMAs never
 // depend on each other once NN >= 2).  The outputs overwrite `cur` in place -- they are the next layer's B fragments.
 template <int NN>
 __device__ __forceinline__ void infer_layer(const float* lds, f32x4 (&cur)[IMAXT], int nK, int N, int w_off, int nn,
-                                            int b_off, int act, int c, int q, bool to_tile, float* tile, int s_t) {
+                                            int b_off, int act, int c, int q, int omode, float* tile, int s_t, float* grow) {
     f32x4 acc[NN];
 #pragma unroll
     for (int t = 0; t < NN; ++t) {
@@ -449,14 +453,22 @@ __device__ __forceinline__ void infer_layer(const float* lds, f32x4 (&cur)[IMAXT
 #pragma unroll
     for (int j = 0; j < IMAXT; ++j) {
         if (j < nK) {                                                      // uniform; the block below is straight-line
-            f32x4 w[NN];
+            // weight fragments in groups of up to four tiles (16 registers): a group's reads are requested before its first
+            // MFMA, and four independent accumulators are enough to keep consecutive MFMAs from depending on each other
+            constexpr int GT = NN > 4 ? 4 : NN;
 #pragma unroll
-            for (int t = 0; t < NN; ++t) w[t] = *reinterpret_cast<const f32x4*>(wp + j * bstep + 64 * t);
-            __builtin_amdgcn_sched_barrier(0);                             // all NN reads requested before the first MFMA
+            for (int t0 = 0; t0 < NN; t0 += GT) {
+                f32x4 w[GT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int t = 0; t < GT; ++t)
+                    if (t0 + t < NN) w[t] = *reinterpret_cast<const f32x4*>(wp + j * bstep + 64 * (t0 + t));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < NN; ++t) MFMA16(w[t][e], cur[j][e], acc[t]);
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < GT; ++t)
+                        if (t0 + t < NN) MFMA16(w[t][e], cur[j][e], acc[t0 + t]);
+            }
         }
     }
 #pragma unroll
@@ -464,7 +476,9 @@ __device__ __forceinline__ void infer_layer(const float* lds, f32x4 (&cur)[IMAXT
         float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
         act_fwd4(act, v);                                                  // y = act(x.W + b), layer.py:368
         const int col0 = 16 * t + 4 * q;
-        if (to_tile) {
+        if (omode == 2) {                                                  // last layer, straight to this lane's row (N % 4 == 0)
+            if (grow && col0 < N) *reinterpret_cast<f32x4*>(grow + col0) = f32x4{v[0], v[1], v[2], v[3]};
+        } else if (omode == 1) {
             *reinterpret_cast<f32x4*>(tile + c * s_t + col0) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
             // pad columns must be finite zeros: they meet the zero rows of the next layer's image
@@ -474,6 +488,13 @@ __device__ __forceinline__ void infer_layer(const float* lds, f32x4 (&cur)[IMAXT
     }
 }
 
+#ifdef SMRT_STAMPS
+#define IST(i) do { if (a.dbg && blockIdx.x == 0 && tid == 0 && it == 2) { a.dbg[i] = wall_clock64(); a.dbg[32 + i] = clock64(); } } while (0)
+#else
+#define IST(i) do { } while (0)
+#endif
+
+template <int ITHREADS>
 __global__ __launch_bounds__(ITHREADS) void fused_infer_kernel(const InferArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -490,13 +511,51 @@ __global__ __launch_bounds__(ITHREADS) void fused_infer_kernel(const InferArgs a
     const int K = a.K, nK0 = a.st[0].K16 >> 4, k4n = a.st[0].K16 >> 2, last = a.n_stages - 1, Nl = a.st[last].N;
     const int s_t = a.tile_stride;
     float* tile = lds + 4 * a.img_n4 + wave * (16 * s_t);
+    [[maybe_unused]] int it = -1;
 #pragma unroll 1
     for (long blk = (long)blockIdx.x * (ITHREADS / 64) + wave; blk < nblk; blk += wstride) {   // wave-uniform
         const long r0 = blk << 4;
-        // Rows enter and leave through a wave-private LDS tile so that global traffic is whole rows (16 bytes per lane,
-        // consecutive lanes along a row).  Rows past the end shadow the last row (never stored), columns past K are zero.
-        // (no integer division: a row takes 4 or 16 lanes, whichever the row length fills)
-        if (a.in) {
+        ++it;
+        IST(0);
+        f32x4 cur[IMAXT];
+        if (!a.in) {
+            // generate: lane (c, q) DRAWS its own fragments: k-block j, quad q of row c is Philox block 4 j + q of the row
+            // (K = Z is a multiple of 4 and the stream offset is block-aligned: host-checked) -- no z buffer, no launch of
+            // its own in front of this one, no LDS
+            const int kq_n = K >> 2;
+            const bool rowok = r0 + c < a.n;
+            const uint64_t qb = (a.gen_elem0 + (uint64_t)(r0 + c) * K) >> 2;
+#pragma unroll
+            for (int j = 2; j < IMAXT; ++j) cur[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                                              // K <= 32 (host-checked)
+                cur[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j < nK0) {                                                         // uniform
+                    const int kq = 4 * j + q;
+                    const uint64_t qi = qb + (uint64_t)kq;
+                    const Philox4 p = philox4x32_10((uint32_t)qi, (uint32_t)(qi >> 32), 0u, STREAM_GENERATE,
+                                                    (uint32_t)a.gen_seed, (uint32_t)(a.gen_seed >> 32));
+                    float n0, n1, n2, n3;
+                    box_muller(p.x, p.y, n0, n1);
+                    box_muller(p.z, p.w, n2, n3);
+                    if (kq < kq_n && rowok)
+                        cur[j] = f32x4{shift_scale(a.gen_loc, a.gen_scale, n0), shift_scale(a.gen_loc, a.gen_scale, n1),
+                                       shift_scale(a.gen_loc, a.gen_scale, n2), shift_scale(a.gen_loc, a.gen_scale, n3)};
+                }
+            }
+        } else if (a.vec_in) {
+            // whole quads straight from global memory into the fragments (K % 4 == 0, ldin % 4 == 0, aligned): every row
+            // gets 64 contiguous bytes per load instruction.  Rows past the end shadow the last row (never stored).
+            const float* src = a.in + min(r0 + c, a.n - 1) * a.ldin + 4 * q;
+#pragma unroll
+            for (int j = 0; j < IMAXT; ++j) {
+                cur[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j < nK0 && 16 * j + 4 * q < K) cur[j] = *reinterpret_cast<const f32x4*>(src + 16 * j);
+            }
+        } else {
+            // Ragged rows enter through a wave-private LDS tile so that global traffic is whole rows (16 bytes per lane,
+            // consecutive lanes along a row).  Rows past the end shadow the last row (never stored), columns past K are zero.
+            // (no integer division: a row takes 4 or 16 lanes, whichever the row length fills)
             const int sh = (k4n >= 16) ? 4 : 2, lpr = 1 << sh, rpi = 64 >> sh;         // lanes per row, rows per instruction
             const int lr = lane >> sh, lc = lane & (lpr - 1);
             for (int rr = 0; rr < 16; rr += rpi) {
@@ -510,69 +569,40 @@ __global__ __launch_bounds__(ITHREADS) void fused_infer_kernel(const InferArgs a
                     *reinterpret_cast<f32x4*>(tile + r * s_t + c4) = v;
                 }
             }
-        } else {
-            // generate: the 16 latent rows are drawn here, one Philox block = four consecutive normals per lane and round
-            // (K = Z is a multiple of 4 and the stream offset is block-aligned: host-checked) -- no z buffer, no launch of
-            // its own in front of this one
-            const int kq_n = K >> 2;
-            for (int i = lane; i < 16 * k4n; i += 64) {
-                const int r = i / k4n, kq = i - r * k4n;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kq < kq_n && r0 + r < a.n) {
-                    const uint64_t q = ((a.gen_elem0 + (uint64_t)(r0 + r) * K) >> 2) + kq;
-                    const Philox4 p = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), 0u, STREAM_GENERATE,
-                                                    (uint32_t)a.gen_seed, (uint32_t)(a.gen_seed >> 32));
-                    float n0, n1, n2, n3;
-                    box_muller(p.x, p.y, n0, n1);
-                    box_muller(p.z, p.w, n2, n3);
-                    v = f32x4{a.gen_loc + a.gen_scale * n0, a.gen_loc + a.gen_scale * n1,
-                              a.gen_loc + a.gen_scale * n2, a.gen_loc + a.gen_scale * n3};
-                }
-                *reinterpret_cast<f32x4*>(tile + r * s_t + 4 * kq) = v;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");             // written by other lanes of this wave
-        __builtin_amdgcn_wave_barrier();
-        f32x4 cur[IMAXT];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");             // written by other lanes of this wave
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < IMAXT; ++j) {
-            cur[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (j < nK0) cur[j] = *reinterpret_cast<const f32x4*>(tile + c * s_t + 16 * j + 4 * q);
+            for (int j = 0; j < IMAXT; ++j) {
+                cur[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j < nK0) cur[j] = *reinterpret_cast<const f32x4*>(tile + c * s_t + 16 * j + 4 * q);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        IST(2);
+        float* const grow = (a.vec_out && r0 + c < a.n) ? a.out0 + (r0 + c) * a.ld0 : nullptr;
 #pragma unroll 1
         for (int s = 0; s <= last; ++s) {
             const int nK = UNI(a.st[s].K16) >> 4, N = UNI(a.st[s].N), nN = UNI(a.st[s].N16) >> 4, w_off = UNI(a.st[s].w_off),
                       nn = UNI(a.st[s].nn), b_off = UNI(a.st[s].b_off), act = UNI(a.st[s].act);
-            const bool tt = (s == last);
+            const int tt = (s == last) ? (a.vec_out ? 2 : 1) : 0;
             switch (nN) {
-                case 1: infer_layer<1>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
-                case 2: infer_layer<2>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
-                case 3: infer_layer<3>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
-                case 4: infer_layer<4>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
-                case 5: infer_layer<5>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
-                case 6: infer_layer<6>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
-                case 7: infer_layer<7>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
-                default: infer_layer<8>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t); break;
+                case 1: infer_layer<1>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t, grow); break;
+                case 2: infer_layer<2>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t, grow); break;
+                case 3: infer_layer<3>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t, grow); break;
+                case 4: infer_layer<4>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t, grow); break;
+                case 5: infer_layer<5>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t, grow); break;
+                case 6: infer_layer<6>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t, grow); break;
+                case 7: infer_layer<7>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t, grow); break;
+                default: infer_layer<8>(lds, cur, nK, N, w_off, nn, b_off, act, c, q, tt, tile, s_t, grow); break;
             }
+            IST(3 + s);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // the tile holds the last layer's [16][N] block
-        if (a.vec_out) {
-            const int n4 = Nl >> 2;
-            const int sh = (n4 >= 16) ? 4 : 2, lpr = 1 << sh, rpi = 64 >> sh;
-            const int lr = lane >> sh, lc = lane & (lpr - 1);
-            for (int rr = 0; rr < 16; rr += rpi) {
-                const int r = rr + lr;
-                if (r0 + r < a.n) {
-                    float* dst = a.out0 + (r0 + r) * a.ld0;
-                    for (int m = lc; m < n4; m += lpr)
-                        *reinterpret_cast<f32x4*>(dst + 4 * m) = *reinterpret_cast<const f32x4*>(tile + r * s_t + 4 * m);
-                }
-            }
-        } else {
+        IST(10);
+        if (!a.vec_out) {
+            // encode (mu | log_sigma into two arrays) and ragged widths: the tile holds the last layer's [16][N] block
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             const int lr = lane >> 4, lc = lane & 15;
             for (int rr = 0; rr < 16; rr += 4) {
                 const int r = rr + lr;
@@ -584,25 +614,36 @@ __global__ __launch_bounds__(ITHREADS) void fused_infer_kernel(const InferArgs a
                     }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");             // the tile is rewritten by the next block of rows
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");             // the tile is rewritten by the next block of rows
-        __builtin_amdgcn_wave_barrier();
+        IST(11);
     }
 }
 
-int launch_fused_infer(hipStream_t s, const InferArgs& a) {
-    const int lds_bytes = a.img_n4 * 16 + (ITHREADS / 64) * 16 * a.tile_stride * (int)sizeof(float);
-    if (a.maxt > IMAXT || lds_bytes > 160 * 1024) return -1;               // the caller takes the per-layer path
+template <int ITHREADS>
+static int launch_fused_infer_t(hipStream_t s, const InferArgs& a, int lds_bytes) {
     if (lds_bytes > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(fused_infer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            lds_bytes) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fused_infer_kernel<ITHREADS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess) {
         (void)hipGetLastError();
         return -1;
     }
     const long nblk = (a.n + 15) >> 4;
     const long wgs = (nblk + ITHREADS / 64 - 1) / (ITHREADS / 64);
-    SMRT_LAUNCH(fused_infer_kernel, dim3((unsigned)std::min<long>(wgs, 256)), dim3(ITHREADS), (size_t)lds_bytes, s, a);
+    SMRT_LAUNCH(fused_infer_kernel<ITHREADS>, dim3((unsigned)std::min<long>(wgs, 256)), dim3(ITHREADS), (size_t)lds_bytes, s, a);
     return 0;
+}
+
+int launch_fused_infer(hipStream_t s, const InferArgs& a) {
+    if (a.maxt > IMAXT) return -1;                                         // the caller takes the per-layer path
+    // the wave-private tiles are only touched by ragged input rows / split or ragged output rows
+    const bool tiles = !((!a.in || a.vec_in) && a.vec_out);
+    const int tile_bytes = tiles ? 16 * a.tile_stride * (int)sizeof(float) : 0;
+    const int lds16 = a.img_n4 * 16 + 16 * tile_bytes, lds8 = a.img_n4 * 16 + 8 * tile_bytes;
+    if (lds16 <= 160 * 1024) return launch_fused_infer_t<1024>(s, a, lds16);
+    if (lds8 <= 160 * 1024) return launch_fused_infer_t<512>(s, a, lds8);
+    return -1;
 }
 
 int dw_opt_blocks(int total_tiles) { return (total_tiles + 3) / 4; }

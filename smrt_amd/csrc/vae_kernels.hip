@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void sample_normal_kernel(float* out, long ld,
     box_muller(p.x, p.y, v[0], v[1]);
     box_muller(p.z, p.w, v[2], v[3]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = loc + scale * v[e];
+    for (int e = 0; e < 4; ++e) v[e] = shift_scale(loc, scale, v[e]);
     if (i0 >= 0 && i0 + 3 < n && (cols & 3) == 0 && (i0 & 3) == 0 && (ld & 3) == 0) {
         // whole block inside one row, 16-byte aligned (out is 16-byte aligned, ld a multiple of 4)
         const long row = i0 / cols; const int k = (int)(i0 - row * cols);

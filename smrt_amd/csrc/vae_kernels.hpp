@@ -344,12 +344,14 @@ struct InferArgs {
     long n;                               // rows
     float* out0; long ld0; int split;     // output columns [0, split) -> out0, [split, N) -> out1 (encode: mu | log_sigma)
     float* out1; long ld1;
+    int vec_in;                           // input rows are whole aligned quads (K % 4 == 0, ldin % 4 == 0, 16-byte aligned)
     int vec_out;                          // out0 takes whole 16-byte stores (split == N, N % 4 == 0, ld0 % 4 == 0, aligned)
     int tile_stride;                      // floats per row of the wave-private I/O tile: max(rup16(K), rup16(N_last)) + 4
     int maxt;                             // widest activation of the chain in 16-column tiles (kernel variant: 8 or 16)
     // generate: in == nullptr -> the input rows are DRAWN in the kernel, z = loc + scale * N(0,1) from the Philox stream
     // (seed, stream 3, step 0) at element gen_elem0 + row * K + k (K % 4 == 0 and gen_elem0 % 4 == 0: whole Philox blocks)
     uint64_t gen_seed, gen_elem0; float gen_loc, gen_scale;
+    unsigned long long* dbg;              // diagnostic builds only (-DSMRT_STAMPS)
 };
 int  launch_fused_infer(hipStream_t s, const InferArgs& a);
 int  dw_opt_blocks(int total_tiles);
