@@ -1418,6 +1418,9 @@ static int infer_fused(smrt_vae* h, int l0, int l1, const float* in, long ldin, 
         (void)hipMemcpy(hb, idbg, 64 * 8, hipMemcpyDeviceToHost);
         static int once = 0;
         if (once++ < 2 && n > 100000) {
+            fprintf(stderr, "infer wg0: staged +%.2f us, wave 0 done +%.2f us; last wg: entry +%.2f, staged +%.2f, wave 0 done +%.2f us\n",
+                    (double)(hb[21] - hb[20]) * 0.01, (double)(hb[22] - hb[20]) * 0.01, (double)((long long)hb[24] - (long long)hb[20]) * 0.01,
+                    (double)((long long)hb[25] - (long long)hb[20]) * 0.01, (double)((long long)hb[26] - (long long)hb[20]) * 0.01);
             const int ids[] = {0, 1, 2, 3, 4, 5, 6, 10, 11};
             int prev = 0;
             for (int k = 1; k < 9; ++k) {

@@ -490,8 +490,10 @@ __device__ __forceinline__ void infer_layer(const float* lds, f32x4 (&cur)[IMAXT
 
 #ifdef SMRT_STAMPS
 #define IST(i) do { if (a.dbg && blockIdx.x == 0 && tid == 0 && it == 2) { a.dbg[i] = wall_clock64(); a.dbg[32 + i] = clock64(); } } while (0)
+#define IWG(i) do { if (a.dbg && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) a.dbg[(blockIdx.x == 0 ? 20 : 24) + i] = wall_clock64(); } while (0)
 #else
 #define IST(i) do { } while (0)
+#define IWG(i) do { } while (0)
 #endif
 
 template <int ITHREADS>
@@ -500,20 +502,25 @@ __global__ __launch_bounds__(ITHREADS) void fused_infer_kernel(const InferArgs a
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = UNI(tid >> 6);
     const int c = lane & 15, q = lane >> 4;
+    IWG(0);
     {
         const float4* src = reinterpret_cast<const float4*>(a.img);
         float4* dst = reinterpret_cast<float4*>(lds);
         for (int i = tid; i < a.img_n4; i += ITHREADS) dst[i] = src[i];
     }
     __syncthreads();
+    IWG(1);
     const long nblk = (a.n + 15) >> 4;
+    // 16-row blocks go round-robin over (wave index, workgroup): block b belongs to wave (b / gridDim.x) % waves of workgroup
+    // b % gridDim.x, so the ragged last round (2 838 of 4 096 wave slots for C2's rows) leaves every SIMD of the chip with
+    // 10 or 11 blocks instead of 12 on some CUs and 8 on others
     const long wstride = (long)gridDim.x * (ITHREADS / 64);
     const int K = a.K, nK0 = a.st[0].K16 >> 4, k4n = a.st[0].K16 >> 2, last = a.n_stages - 1, Nl = a.st[last].N;
     const int s_t = a.tile_stride;
     float* tile = lds + 4 * a.img_n4 + wave * (16 * s_t);
     [[maybe_unused]] int it = -1;
 #pragma unroll 1
-    for (long blk = (long)blockIdx.x * (ITHREADS / 64) + wave; blk < nblk; blk += wstride) {   // wave-uniform
+    for (long blk = (long)wave * gridDim.x + blockIdx.x; blk < nblk; blk += wstride) {         // wave-uniform
         const long r0 = blk << 4;
         ++it;
         IST(0);
@@ -619,6 +626,7 @@ __global__ __launch_bounds__(ITHREADS) void fused_infer_kernel(const InferArgs a
         }
         IST(11);
     }
+    IWG(2);
 }
 
 template <int ITHREADS>
