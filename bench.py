@@ -228,6 +228,27 @@ def dp_c4_throughput(dist, dev, rank, world, rows_per_gpu=262144, global_batch=6
         sess.close()
 
 
+def other_nets():
+    """The other networks of BASELINE.json's configs, driver-timed in this run (rank 0, one GPU):
+    N1 = 784-450-(10,10)-450-784 (the reference's own test network, smrt/balance/tests/test_smrt.py:17-21) at the reference's
+    default batch 128 (one class of C3: 5000 rows), at batch 256 on C1's 500 minority rows, and N5 = 256-[1024]*4-(64,64) at
+    one 65 536-row mini-batch.  Each with its own fraction of the fp32 MFMA peak (6 P - 2 D h1 FLOP per sample)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import bench_configs as bc
+    out = {}
+    for name, net, rows, batch, opt, epochs in (("train_n1_b128", "N1", 5000, 128, "rms_prop", 20),
+                                                ("train_n1_b256", "N1", 500, 256, "rms_prop", 50),
+                                                ("train_n5_b65536", "N5", 131072, 65536, "adam", 2)):
+        r = bc.case_train(name, net, rows, batch, opt, epochs)
+        steps = -(-rows // batch)
+        out[name] = {"net": net, "rows": rows, "batch": batch, "optimizer": opt, "epochs": epochs,
+                     "samples_per_s": r["samples_per_s"], "ms_per_epoch": r["ms_per_epoch_wall"],
+                     "us_per_minibatch": 1e3 * r["ms_per_epoch_wall"] / steps,
+                     "launches_per_minibatch": sum(v["launches"] for k, v in r["kernels"].items() if k != "finalize") / steps,
+                     "tflops": r["tflops"], "frac": r["mfma_frac"]}
+    return out
+
+
 def balance_wallclock(with_cpu):
     """End-to-end smrt_balance(X, y, 128, 16) on C2, host arrays in -> host arrays out (API defaults: 20 epochs, batch
     128, rms_prop, balance_ratio 0.2 -> 176 470 synthetic rows, shuffled fp64 output of 1 176 470 x 64).  Median of 3 after
@@ -492,6 +513,12 @@ def main():
             c4 = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0:
             out["dp_c4"] = c4
+        if rank == 0 and world == 1:
+            note(rank, "leg other_nets")
+            try:
+                out["other_nets"] = other_nets()
+            except Exception as e:      # noqa: BLE001
+                out["other_nets"] = {"error": "%s: %s" % (type(e).__name__, e)}
         note(rank, "legs done")
         dog.cancel()
         faulthandler.cancel_dump_traceback_later()
