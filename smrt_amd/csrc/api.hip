@@ -310,17 +310,65 @@ static int dw_tiles(const smrt_vae* h, int t) {
     return tot;
 }
 static bool dw_big(const smrt_vae* h, int rows) { return rows >= 2048 && dw_tiles(h, 128) >= 48; }
-// Split-K factor of the weight-gradient launch: tiles x splits workgroups should fill a whole number of "rounds" of
-// the chip (256 CUs x 2 resident workgroups): 440 tiles x 3 splits is 2.6 rounds and runs as long as 3.
+// Work units of the tiled weight-gradient launch for a base split factor S (the number of K ranges of an INTERIOR tile):
+// a tile whose busiest wave multiplies `cost` of 4 blocks (gemm_tile's arrangements; 4 = full tile) is cut into
+// ceil(S min(4, cost + pen) / 4) ranges, so that every workgroup runs about equally long.  pen = 1 block-time is what the
+// bounds-checked staging of an edge tile costs on top of its MFMAs (measured, N1 at batch 65 536: dW per step 1.09 ms with
+// uniform ranges, 1.24 with pen 0, 1.04 / 0.98 / 1.04 with pen 0.5 / 1 / 1.5-2; SMRT_DW_EDGE_PEN overrides, < 0 = uniform).
+// Returns the number of units; *t_rel = the longest workgroup's time relative to a full tile over all rows.
+static float dw_edge_pen() {
+    static const float v = []() { const char* e = std::getenv("SMRT_DW_EDGE_PEN"); return e ? (float)std::atof(e) : 1.0f; }();
+    return v;
+}
+static int plan_dw_units(const smrt_vae* h, bool big, int S, DwArgs* d, double* t_rel) {
+    const int t = big ? 128 : 64;
+    int units = 0;
+    double worst = 0.0;
+    for (int l = 0; l < h->NL; ++l) {
+        const int fi = h->lay[l].fi, fo = h->lay[l].fo;
+        const int tm = (fi + t - 1) / t, tn = (fo + t - 1) / t;
+        int s_cls[4] = {S, S, S, S};
+        if (big && dw_edge_pen() >= 0.f) {
+            const int MBl = std::min(4, (fi - (tm - 1) * 128 + 31) / 32), NBl = std::min(4, (fo - (tn - 1) * 128 + 31) / 32);
+            auto cost = [](int MB, int NB) { return std::min(std::min(std::min(MB, 2) * std::min(NB, 2), MB), NB); };
+            const int mb[4] = {4, 4, MBl, MBl}, nb[4] = {4, NBl, 4, NBl};
+            for (int c = 0; c < 4; ++c) {
+                const bool edge = mb[c] < 4 || nb[c] < 4;
+                const double w = edge ? std::min(4.0, cost(mb[c], nb[c]) + (double)dw_edge_pen()) : 4.0;
+                s_cls[c] = std::max(1, std::min(S, (int)std::ceil(S * w / 4.0 - 1e-9)));
+                const int n_c = c == 0 ? (tm - 1) * (tn - 1) : (c == 1 ? tm - 1 : (c == 2 ? tn - 1 : 1));
+                if (n_c > 0) worst = std::max(worst, w / 4.0 / s_cls[c]);
+            }
+        } else {
+            worst = std::max(worst, 1.0 / S);
+        }
+        const int n_c[4] = {(tm - 1) * (tn - 1), tm - 1, tn - 1, 1};
+        if (d) {
+            DwLayer& q = d->L[l];
+            q.tiles_m = tm; q.tiles_n = tn;
+            for (int c = 0; c < 4; ++c) {
+                q.s_cls[c] = s_cls[c];
+                for (int y = 0; y < s_cls[c]; ++y) d->ycum[y + 1] += n_c[c];        // (per-range counts; prefix-summed below)
+            }
+        }
+        for (int c = 0; c < 4; ++c) units += n_c[c] * s_cls[c];
+    }
+    if (d) for (int y = 1; y <= 32; ++y) d->ycum[y] += d->ycum[y - 1];
+    if (t_rel) *t_rel = worst;
+    return units;
+}
+// Split-K factor of the weight-gradient launch: the launch lasts rounds x (longest workgroup), rounds = units over the 512
+// workgroups the chip holds at once (256 CUs x 2): 440 tiles x 3 splits is 2.6 rounds and runs as long as 3.
 static int choose_splits(const smrt_vae* h, int rows) {
-    const int T = dw_tiles(h, dw_big(h, rows) ? 128 : 64);
+    const bool big = dw_big(h, rows);
     const int slots = 512;
     const int smax = std::max(1, std::min(32, rows / 512));          // keep >= 512 rows (16 K-tiles) per split
-    int best = 1; double best_eff = 0.0;
+    int best = 1; double best_t = 1e30;
     for (int s = 1; s <= smax; ++s) {
-        const double r = (double)T * s / slots;
-        const double eff = r / std::ceil(r);
-        if (eff > best_eff + 0.02) { best_eff = eff; best = s; }    // smaller split (less slab traffic) on near ties
+        double t_rel;
+        const int units = plan_dw_units(h, big, s, nullptr, &t_rel);
+        const double t = std::ceil((double)units / slots) * t_rel;
+        if (t < best_t * 0.98) { best_t = t; best = s; }             // smaller split (less slab traffic) on near ties
     }
     return best;
 }
@@ -721,6 +769,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         d.n_layers = NL; d.total_tiles = tb; d.rows = rows; d.splits = splits;
         d.k_per_split = (((rows + splits - 1) / splits) + 31) & ~31;
         d.slab_stride = h->P_int;
+        if (!small) d.total_tiles = plan_dw_units(h, big, splits, &d, nullptr);      // (tile, K range) work units
         { ProfScope ps(h, PK_DW); if (small) launch_small_dw(s, d); else launch_dw(s, d, big); } ++launches;
     }
     if (mode == 1) {

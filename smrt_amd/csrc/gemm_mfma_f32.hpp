@@ -147,13 +147,33 @@ __device__ __forceinline__ void read_frag(const float* lds, int base_mn, int kb,
     }
 }
 
+// ------------------------------------------------------------------ wave -> 32x32 block arrangements
+// A wave owns up to four 32x32 blocks of the tile (accumulator slot s = WN * i + j).  Which ones is the tile's ARRANGEMENT,
+// chosen once per workgroup (uniform):
+//   0  2x2 : wave (wr, wc) owns rows 32 (WM wr + i), columns 32 (WN wc + j)            -- every interior tile
+//   1  row owner (128x128 tiles only): wave w owns row block w, column blocks s = 0..   -- tiles with few real COLUMN blocks
+//   2  column owner (128x128 only):    wave w owns column block w, row blocks s = 0..   -- tiles with few real ROW blocks
+// In an edge tile of a 784 / 450 / 20 / 10-wide layer only MB x NB of the 4 x 4 blocks hold a real element.  Under 2x2 the
+// tile lasts as long as its busiest wave, min(MB,2) min(NB,2) blocks; a row-owner tile lasts NB, a column-owner tile MB
+// blocks: 66 real columns (3 blocks) take 3 block-times instead of 4, 16 real columns 1 instead of 2.
+template <int WM, int WN>
+__device__ __forceinline__ int blk_row(int arr, int wave, int i, int j) {
+    return arr == 0 ? (wave >> 1) * 32 * WM + i * 32 : (arr == 1 ? wave * 32 : (WN * i + j) * 32);
+}
+template <int WM, int WN>
+__device__ __forceinline__ int blk_col(int arr, int wave, int i, int j) {
+    return arr == 0 ? (wave & 1) * 32 * WN + j * 32 : (arr == 1 ? (WN * i + j) * 32 : wave * 32);
+}
+
 // ------------------------------------------------------------------ block-tile main loop
 // Accumulates A[m0.., kbeg..kend) * B[kbeg..kend), n0..) into acc[WM][WN].
 // bsum (optional): per-thread running sums over k of the B values this thread stages (Stage::add_to) -- the
 // weight-gradient kernel turns them into the bias gradient (column sums of dPre) without an extra row of MFMA tiles.
 // LI x LJ: how many of this wave's 32-row / 32-column blocks are multiplied (the rest lie wholly in the padding of an edge
 // tile; their accumulators stay zero).  Compile-time, so the main loop has no branch in it -- see gemm_tile below.
-template <int ALAY, int BLAY, int WM, int WN, bool A_ONES, int LI, int LJ>
+// ARR: the arrangement above (1: LI == 1 and LJ column blocks from the tile's left edge; 2: LJ == 1 and LI row blocks from
+// the top); the product of row fragment i and column fragment j goes to accumulator slot i + j there.
+template <int ALAY, int BLAY, int WM, int WN, bool A_ONES, int LI, int LJ, int ARR = 0>
 __device__ __forceinline__ void gemm_tile_impl(const float* __restrict__ A, long lda, int M_data,
                                                const float* __restrict__ B, long ldb, int N_data,
                                                int m0, int n0, int kbeg, int kend,
@@ -204,19 +224,22 @@ __device__ __forceinline__ void gemm_tile_impl(const float* __restrict__ A, long
         // Fragments of k-block kb+1 are requested before the MFMAs of k-block kb; the asm (which the tile addresses
         // escape into, so its memory clobber covers them) and the scheduling barrier pin that order.  Left alone,
         // hipcc sinks each LDS read to just before its MFMA and every group of MFMAs waits out a full LDS latency.
-        float fa[2][WM][4], fb[2][WN][4];
+        constexpr int FI = ARR == 0 ? WM : (LI > 0 ? LI : 1), FJ = ARR == 0 ? WN : (LJ > 0 ? LJ : 1);
+        const int abase = ARR == 0 ? wr * 32 * WM : (ARR == 1 ? wave * 32 : 0);
+        const int bbase = ARR == 0 ? wc * 32 * WN : (ARR == 2 ? wave * 32 : 0);
+        float fa[2][FI][4], fb[2][FJ][4];
 #pragma unroll
-        for (int i = 0; i < WM; ++i) read_frag<ALAY, BM>(la, wr * 32 * WM + i * 32, 0, r, h, fa[0][i]);
+        for (int i = 0; i < FI; ++i) read_frag<ALAY, BM>(la, abase + i * 32, 0, r, h, fa[0][i]);
 #pragma unroll
-        for (int j = 0; j < WN; ++j) read_frag<BLAY, BN>(lb, wc * 32 * WN + j * 32, 0, r, h, fb[0][j]);
+        for (int j = 0; j < FJ; ++j) read_frag<BLAY, BN>(lb, bbase + j * 32, 0, r, h, fb[0][j]);
 #pragma unroll
         for (int kb = 0; kb < BK / 8; ++kb) {
             const int cur = kb & 1, nxt = cur ^ 1;
             if (kb + 1 < BK / 8) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i) read_frag<ALAY, BM>(la, wr * 32 * WM + i * 32, kb + 1, r, h, fa[nxt][i]);
+                for (int i = 0; i < FI; ++i) read_frag<ALAY, BM>(la, abase + i * 32, kb + 1, r, h, fa[nxt][i]);
 #pragma unroll
-                for (int j = 0; j < WN; ++j) read_frag<BLAY, BN>(lb, wc * 32 * WN + j * 32, kb + 1, r, h, fb[nxt][j]);
+                for (int j = 0; j < FJ; ++j) read_frag<BLAY, BN>(lb, bbase + j * 32, kb + 1, r, h, fb[nxt][j]);
             }
             asm volatile("" :: "v"(ldsA), "v"(ldsB) : "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -225,8 +248,10 @@ __device__ __forceinline__ void gemm_tile_impl(const float* __restrict__ A, long
 #pragma unroll
                 for (int i = 0; i < LI; ++i)
 #pragma unroll
-                    for (int j = 0; j < LJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < LJ; ++j) {
+                        f32x16& d = ARR == 0 ? acc[i][j] : acc[(i + j) / WN][(i + j) % WN];
+                        d = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], d, 0, 0, 0);
+                    }
         }
         if (more) {
             const bool fk = (k0 + 2 * BK <= kend);
@@ -241,43 +266,61 @@ __device__ __forceinline__ void gemm_tile_impl(const float* __restrict__ A, long
 }
 
 // Edge tiles of 784 / 450 / 20 / 10-wide layers are mostly padding (16 real columns in the last 128 of 784): a wave
-// multiplies only the blocks of its region that hold a real element.  The choice is made ONCE per tile, between complete
-// copies of the main loop (a branch around the MFMA group inside one loop makes hipcc spill the accumulators); it is
+// multiplies only the blocks of its region that hold a real element, and a 128x128 edge tile takes the arrangement that
+// spreads its real blocks evenly over the four waves (returned: the epilogue maps accumulators through blk_row / blk_col).
+// The choice is made ONCE per tile, between complete copies of the main loop (a branch around the MFMA group inside one loop makes hipcc spill the accumulators); it is
 // wave-uniform, and every copy passes the same barriers, so the waves of a workgroup may take different copies.
 template <int ALAY, int BLAY, int WM, int WN, bool A_ONES>
-__device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda, int M_data,
-                                          const float* __restrict__ B, long ldb, int N_data,
-                                          int m0, int n0, int kbeg, int kend,
-                                          float* ldsA, float* ldsB, f32x16 (&acc)[WM][WN], float4* bsum = nullptr) {
-    const int wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+__device__ __forceinline__ int gemm_tile(const float* __restrict__ A, long lda, int M_data,
+                                         const float* __restrict__ B, long ldb, int N_data,
+                                         int m0, int n0, int kbeg, int kend,
+                                         float* ldsA, float* ldsB, f32x16 (&acc)[WM][WN], float4* bsum = nullptr) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wr = wave >> 1, wc = wave & 1;
+#define SMRT_TILE(LI_, LJ_, ARR_) gemm_tile_impl<ALAY, BLAY, WM, WN, A_ONES, LI_, LJ_, ARR_>(A, lda, M_data, B, ldb, N_data, m0, n0, kbeg, kend, ldsA, ldsB, acc, bsum)
+    if constexpr (WM == 2 && WN == 2) {
+        // real 32-row / 32-column blocks of this tile, and the arrangement under which its busiest wave has the fewest
+        const int MB = min(4, (M_data + (A_ONES ? 1 : 0) - m0 + 31) >> 5), NB = min(4, (N_data - n0 + 31) >> 5);
+        const int c0 = min(MB, 2) * min(NB, 2);
+        if (NB < c0 && NB <= MB) {                  // row owners: wave w multiplies row block w by column blocks 0 .. NB-1
+            if (wave >= MB) SMRT_TILE(0, 0, 0);
+            else if (NB == 1) SMRT_TILE(1, 1, 1);
+            else if (NB == 2) SMRT_TILE(1, 2, 1);
+            else SMRT_TILE(1, 3, 1);
+            return 1;
+        }
+        if (MB < c0) {                              // column owners: wave w multiplies row blocks 0 .. MB-1 by column block w
+            if (wave >= NB) SMRT_TILE(0, 0, 0);
+            else if (MB == 1) SMRT_TILE(1, 1, 2);
+            else if (MB == 2) SMRT_TILE(2, 1, 2);
+            else SMRT_TILE(3, 1, 2);
+            return 2;
+        }
+    }
     const int rem_m = M_data + (A_ONES ? 1 : 0) - (m0 + wr * 32 * WM), rem_n = N_data - (n0 + wc * 32 * WN);
     const int li = __builtin_amdgcn_readfirstlane(rem_m <= 0 ? 0 : min(WM, (rem_m + 31) >> 5));
     const int lj = __builtin_amdgcn_readfirstlane(rem_n <= 0 ? 0 : min(WN, (rem_n + 31) >> 5));
-#define SMRT_TILE(LI_, LJ_) gemm_tile_impl<ALAY, BLAY, WM, WN, A_ONES, LI_, LJ_>(A, lda, M_data, B, ldb, N_data, m0, n0, kbeg, kend, ldsA, ldsB, acc, bsum)
-    if (li == WM && lj == WN) { SMRT_TILE(WM, WN); return; }
-    if constexpr (WM == 2) { if (li == 2 && lj == 1) { SMRT_TILE(2, 1); return; } }
-    if constexpr (WN == 2) { if (li == 1 && lj == 2) { SMRT_TILE(1, 2); return; } }
-    if constexpr (WM == 2 || WN == 2) { if (li == 1 && lj == 1) { SMRT_TILE(1, 1); return; } }
-    SMRT_TILE(0, 0);            // nothing of this wave's region is real: it still stages its share of both operands
+    if (li == WM && lj == WN) { SMRT_TILE(WM, WN, 0); return 0; }
+    if constexpr (WM == 2) { if (li == 2 && lj == 1) { SMRT_TILE(2, 1, 0); return 0; } }
+    if constexpr (WN == 2) { if (li == 1 && lj == 2) { SMRT_TILE(1, 2, 0); return 0; } }
+    if constexpr (WM == 2 || WN == 2) { if (li == 1 && lj == 1) { SMRT_TILE(1, 1, 0); return 0; } }
+    SMRT_TILE(0, 0, 0);         // nothing of this wave's region is real: it still stages its share of both operands
 #undef SMRT_TILE
+    return 0;
 }
 
-// Visit every accumulator element of this thread: f(row, col, value) with global row/col.
+// Visit every accumulator element of this thread: f(row, col, value) with global row/col (`arr`: what gemm_tile returned).
 template <int WM, int WN, class F>
-__device__ __forceinline__ void for_each_c(const f32x16 (&acc)[WM][WN], int m0, int n0, F&& f) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void for_each_c(const f32x16 (&acc)[WM][WN], int m0, int n0, int arr, F&& f) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN; ++j) {
+            const int rb = m0 + blk_row<WM, WN>(arr, wave, i, j), cb = n0 + blk_col<WM, WN>(arr, wave, i, j);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wr * 32 * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int col = n0 + wc * 32 * WN + j * 32 + r;
-                f(row, col, acc[i][j][e]);
-            }
+            for (int e = 0; e < 16; ++e) f(rb + (e & 3) + 8 * (e >> 2) + 4 * h, cb + r, acc[i][j][e]);
+        }
 }
 
 }  // namespace smrt

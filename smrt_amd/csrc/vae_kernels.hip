@@ -36,7 +36,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
     const unsigned long long c_beg = clock64(), w_beg = wall_clock64();
 #endif
     f32x16 acc[WM][WN];
-    gemm_tile<ALAY, BLAY, WM, WN, false>(a.A, a.lda, a.M, a.B, a.ldb, a.N, m0, n0, 0, a.K, ldsA, ldsB, acc);
+    const int arr = gemm_tile<ALAY, BLAY, WM, WN, false>(a.A, a.lda, a.M, a.B, a.ldb, a.N, m0, n0, 0, a.K, ldsA, ldsB, acc);
 
 #ifdef SMRT_STAMPS
     if (a.dbg && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 1) {     // main-loop clock of one workgroup
@@ -47,40 +47,52 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
         // y = act(x.W + b)                                                     layer.py:368
         // The bias is fetched once per column (the stores to C may alias it as far as the compiler knows, so inside
         // the element loop it would be re-loaded 16 times) and interior tiles skip the bounds checks.
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        float bj[WN];
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        if (m0 + BM <= a.M && n0 + BN <= a.N) {             // (interior: arrangement 0)
+            float bj[WN];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + (wave & 1) * 32 * WN + j * 32 + (lane & 31);
-            bj[j] = (col < a.N) ? a.bias[col] : 0.0f;
-        }
-        if (m0 + BM <= a.M && n0 + BN <= a.N) {
-            for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+            for (int j = 0; j < WN; ++j) bj[j] = a.bias[n0 + (wave & 1) * 32 * WN + j * 32 + (lane & 31)];
+            for_each_c<WM, WN>(acc, m0, n0, 0, [&](int row, int col, float v) {
                 const int j = ((col - n0) >> 5) % WN;
                 a.C[(long)row * a.ldc + col] = act_fwd(a.act, v + bj[j]);
             });
         } else {
-            for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-                const int j = ((col - n0) >> 5) % WN;
-                if (row < a.M && col < a.N) a.C[(long)row * a.ldc + col] = act_fwd(a.act, v + bj[j]);
-            });
+            const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const int col = n0 + blk_col<WM, WN>(arr, wave, i, j) + r;
+                    const int rowb = m0 + blk_row<WM, WN>(arr, wave, i, j) + 4 * h;
+                    const float b = a.bias[min(col, a.N - 1)];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = rowb + (e & 3) + 8 * (e >> 2);
+                        if (row < a.M && col < a.N) a.C[(long)row * a.ldc + col] = act_fwd(a.act, acc[i][j][e] + b);
+                    }
+                }
         }
     } else if constexpr (EPI == EPI_HEADS_SPLIT) {
         // fused (z_mean | z_log_sigma) heads written to two contiguous [n][Z] outputs   autoencoder.py:500
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        float bj[WN];
+        const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int col = n0 + (wave & 1) * 32 * WN + j * 32 + (lane & 31);
-            bj[j] = a.bias[min(col, a.N - 1)];
-        }
-        for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
-            if (row < a.M && col < a.N) {
-                const float y = act_fwd(a.act, v + bj[((col - n0) >> 5) % WN]);
-                if (col < a.Z) a.C[(long)row * a.Z + col] = y;
-                else           a.out2[(long)row * a.Z + (col - a.Z)] = y;
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int col = n0 + blk_col<WM, WN>(arr, wave, i, j) + r;
+                const int rowb = m0 + blk_row<WM, WN>(arr, wave, i, j) + 4 * h;
+                const float b = a.bias[min(col, a.N - 1)];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = rowb + (e & 3) + 8 * (e >> 2);
+                    if (row < a.M && col < a.N) {
+                        const float y = act_fwd(a.act, acc[i][j][e] + b);
+                        if (col < a.Z) a.C[(long)row * a.Z + col] = y;
+                        else           a.out2[(long)row * a.Z + (col - a.Z)] = y;
+                    }
+                }
             }
-        });
     } else if constexpr (EPI == EPI_BCE) {
         // last decoder layer: p = sigmoid(.), clipped Bernoulli NLL summed into a block partial, and
         // dL/dpre emitted directly.                     layer.py:333-338, _ae_utils.py:31-32
@@ -123,13 +135,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
             // the loss sum are predicated.  A load inside the bounds check is waited for on the spot, and a lane with
             // valid columns then walks through its 32-64 elements one memory round trip at a time.
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+            const int r = lane & 31, h = lane >> 5;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    const int col = n0 + wc * 32 * WN + j * 32 + r, colc = min(col, a.N - 1);
-                    const int rowb = m0 + wr * 32 * WM + i * 32 + 4 * h;
+                    const int col = n0 + blk_col<WM, WN>(arr, wave, i, j) + r, colc = min(col, a.N - 1);
+                    const int rowb = m0 + blk_row<WM, WN>(arr, wave, i, j) + 4 * h;
                     const float b = a.bias[colc];
                     float x[16];
 #pragma unroll
@@ -155,13 +167,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
         float lsum = 0.f;
         {
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+            const int r = lane & 31, h = lane >> 5;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    const int col = n0 + wc * 32 * WN + j * 32 + r, colc = min(col, a.N - 1);
-                    const int rowb = m0 + wr * 32 * WM + i * 32 + 4 * h;
+                    const int col = n0 + blk_col<WM, WN>(arr, wave, i, j) + r, colc = min(col, a.N - 1);
+                    const int rowb = m0 + blk_row<WM, WN>(arr, wave, i, j) + 4 * h;
                     const float b = a.bias[colc];
                     float x[16];                      // targets: one batch from clamped addresses (see BCE)
 #pragma unroll
@@ -206,13 +218,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
         } else {
             // edge tiles: the same batches from clamped addresses, predicated stores (see BCE)
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+            const int r = lane & 31, h = lane >> 5;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    const int col = n0 + wc * 32 * WN + j * 32 + r, colc = min(col, a.N - 1);
-                    const int rowb = m0 + wr * 32 * WM + i * 32 + 4 * h;
+                    const int col = n0 + blk_col<WM, WN>(arr, wave, i, j) + r, colc = min(col, a.N - 1);
+                    const int rowb = m0 + blk_row<WM, WN>(arr, wave, i, j) + 4 * h;
                     float y[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
@@ -231,15 +243,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
         // one batch from clamped addresses (see BCE); sub-tiles that lie wholly past N are skipped (wave-uniform).
         {
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-            const int r = lane & 31, h = lane >> 5, wr = wave >> 1, wc = wave & 1;
+            const int r = lane & 31, h = lane >> 5;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    const int colb = n0 + wc * 32 * WN + j * 32;
+                    const int colb = n0 + blk_col<WM, WN>(arr, wave, i, j);
                     if (colb >= a.N) continue;
                     const int col = colb + r, colc = min(col, a.N - 1);
-                    const int rowb = m0 + wr * 32 * WM + i * 32 + 4 * h;
+                    const int rowb = m0 + blk_row<WM, WN>(arr, wave, i, j) + 4 * h;
                     float mu[16], ls[16], ee[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
@@ -324,15 +336,40 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void dw_kernel(const DwArgs a) {
     __shared__ __align__(16) float ldsA[2 * lds_floats<OUTER, BM>()];
     __shared__ __align__(16) float ldsB[2 * lds_floats<OUTER, BN>()];
 
-    const int t = blockIdx.x;
-    int li = 0;
+    // Work unit -> (layer, tile, K range).  Edge tiles of 784 / 450 / 20 / 10-wide layers multiply 1-3 of their 16 blocks'
+    // worth per wave (gemm_tile's arrangements), so they are cut into FEWER, longer K ranges than interior tiles: every
+    // workgroup of the launch then runs about equally long, and the launch is as long as the chip-wide average, not as long
+    // as an interior tile's range (one round of 512 resident workgroups lasts as long as its slowest member).
+    // Units are ordered K-range-major (all tiles' range 0, then every tile that has a range 1, ...): neighbouring
+    // workgroups then work on neighbouring tiles of the SAME rows and share their operand panels in L2.
+    int y = 0;
 #pragma unroll 1
-    for (int i = 1; i < a.n_layers; ++i) if (t >= a.L[i].tile_begin) li = i;
+    for (int i = 1; i < a.splits; ++i) if ((int)blockIdx.x >= a.ycum[i]) y = i;
+    int v = (int)blockIdx.x - a.ycum[y];
+    int li = 0, tr = 0, tc = 0, S = 1;
+    {
+        bool found = false;
+#pragma unroll 1
+        for (int l = 0; l < a.n_layers && !found; ++l) {
+            const DwLayer& Q = a.L[l];
+            const int tm1 = Q.tiles_m - 1, tn1 = Q.tiles_n - 1;
+            const int n_c[4] = {tm1 * tn1, tm1, tn1, 1};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (found || Q.s_cls[c] <= y) continue;
+                if (v < n_c[c]) {
+                    found = true; li = l; S = Q.s_cls[c];
+                    tr = c == 0 ? v / tn1 : (c == 1 ? v : tm1);
+                    tc = c == 0 ? v - tr * tn1 : (c == 2 ? v : tn1);
+                } else v -= n_c[c];
+            }
+        }
+    }
     const DwLayer& L = a.L[li];
-    const int lt = t - L.tile_begin;
-    const int m0 = (lt / L.tiles_n) * BM, n0 = (lt % L.tiles_n) * BN;
-    const int kbeg = blockIdx.y * a.k_per_split;
-    const int kend = min(a.rows, kbeg + a.k_per_split);
+    const int m0 = tr * BM, n0 = tc * BN;
+    const int kps = (((a.rows + S - 1) / S) + 31) & ~31;
+    const int kbeg = min(a.rows, y * kps);
+    const int kend = min(a.rows, kbeg + kps);
 
     f32x16 acc[WM][WN];
     // The bias gradient is the column sum of dPre: the workgroups of the first row of tiles add up the B values they
@@ -340,11 +377,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void dw_kernel(const DwArgs a) {
     // whenever fan_in is a multiple of the tile height.
     const bool want_db = (m0 == 0);
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    gemm_tile<OUTER, OUTER, WM, WN, false>(L.A, L.lda, L.fi, L.B, L.ldb, L.fo, m0, n0, kbeg, kend, ldsA, ldsB, acc,
-                                           want_db ? &cs : nullptr);
+    const int arr = gemm_tile<OUTER, OUTER, WM, WN, false>(L.A, L.lda, L.fi, L.B, L.ldb, L.fo, m0, n0, kbeg, kend, ldsA, ldsB,
+                                                           acc, want_db ? &cs : nullptr);
 
-    float* C = L.C + (long)blockIdx.y * a.slab_stride;
-    for_each_c<WM, WN>(acc, m0, n0, [&](int row, int col, float v) {
+    float* C = L.C + (long)y * a.slab_stride;
+    for_each_c<WM, WN>(acc, m0, n0, arr, [&](int row, int col, float v) {
         if (row < L.fi && col < L.fo) C[(long)row * L.ldc + col] = v;
     });
     if (want_db) {
@@ -362,10 +399,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void dw_kernel(const DwArgs a) {
             if (col < L.fo) C[(long)L.fi * L.ldc + col] = t;        // row fan_in of the augmented matrix = bias
         }
     }
+    // The optimizer sums a.splits slabs for every element: a tile cut into S < a.splits ranges zeroes its region of the
+    // slabs it does not produce (range y takes slabs S + y, 2 S + y, ...).
+    for (int z = S + y; z < a.splits; z += S) {
+        float* Z = L.C + (long)z * a.slab_stride;
+        const int cq = (threadIdx.x & (BN / 4 - 1)) * 4, r0 = threadIdx.x / (BN / 4);
+        constexpr int RP = GEMM_THREADS / (BN / 4);
+        const int rows_here = min(BM, L.fi - m0);
+        for (int r = r0; r < rows_here; r += RP) {
+            float* dst = Z + (long)(m0 + r) * L.ldc + n0 + cq;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (n0 + cq + c < L.fo) dst[c] = 0.f;
+        }
+        if (want_db && threadIdx.x < BN && n0 + (int)threadIdx.x < L.fo) Z[(long)L.fi * L.ldc + n0 + threadIdx.x] = 0.f;
+    }
 }
 
 void launch_dw(hipStream_t s, const DwArgs& a, bool big) {
-    dim3 grid(a.total_tiles, a.splits);
+    dim3 grid(a.total_tiles);            // (work units: see dw_kernel)
     if (big) SMRT_LAUNCH((dw_kernel<2, 2>), grid, dim3(GEMM_THREADS), 0, s, a);
     else     SMRT_LAUNCH((dw_kernel<1, 1>), grid, dim3(GEMM_THREADS), 0, s, a);
 }

@@ -155,12 +155,17 @@ struct DwLayer {
     int fi, fo;
     long lda, ldb, ldc;
     int tiles_n, tile_begin;
+    // tiled (large-batch) kernel only: work units = (tile, K range).  A tile's class -- interior / last column of tiles /
+    // last row of tiles / corner -- decides into how many K ranges it is cut (see plan_dw_units in api.hip)
+    int tiles_m;
+    int s_cls[4];
 };
 struct DwArgs {
     DwLayer L[MAX_LAYERS];
     int n_layers, total_tiles;
     int rows, k_per_split, splits;
     long slab_stride;
+    int ycum[33];        // tiled kernel: work units in front of K-range index y (units are ordered range-major)
 };
 
 struct OptSeg {
