@@ -96,6 +96,23 @@ def test_c4_shape_one_step_adam_and_its_data_parallel_halves():
     h2.close()
 
 
+def test_edge_tile_arrangements_of_the_tiled_gemm_and_balanced_weight_gradient_units():
+    """Layer widths whose last 128-wide tile holds 1 or 2 real 32-blocks in either direction (700 = 5 x 128 + 60,
+    520 = 4 x 128 + 8, 290 = 2 x 128 + 34) at 16 400 rows (128 row tiles + 16 rows): every row-owner / column-owner
+    arrangement of gemm_tile (N1's 450- and 784-wide layers add the 3- and 1-block cases, test_c4_*), in forward, backward
+    and the weight-gradient launch, whose 96 tiles are cut into class-dependent numbers of K ranges.  One adam step: cost,
+    every gradient and both slots against the oracle at 1e-4."""
+    rs = np.random.RandomState(11)
+    D, hidden, Z, B = 700, [520, 290], 6, 16400
+    o, h = _pair(D, hidden, Z, "sigmoid", "adam", B, rs)
+    p0 = flatten_params(o.params).copy()
+    X, eps = _mnist_shaped(rs, B, d=D), rs.normal(size=(B, Z)).astype(np.float32)
+    c_o, (gW, gb) = o.train_step(X, eps, return_grads=True)
+    c_h, g_h = h.train_step(X, eps, want_grads=True)
+    _check_adam_step(o, h, p0, c_h, g_h, c_o, gW, gb, "edge arrangements 16400 x 700-520-290")
+    h.close()
+
+
 def test_c5_net_one_step_adam_and_generation_of_a_million_rows():
     """Config C5: N5 = 256-[1024]*4-(64,64)-[1024]*4-256.  One adam step at batch 4096 against the oracle; then
     generate(1 000 000): every value finite and in [0, 1] at full size, and four 1024-row blocks spread over the output
