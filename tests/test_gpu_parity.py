@@ -331,6 +331,27 @@ def test_fast_generate_stream():
     h.close()
 
 
+@pytest.mark.parametrize("Z", [4, 12, 24, 32])
+def test_generate_draws_z_inside_the_launch_for_every_quad_count(Z):
+    """Z % 4 == 0 and Z <= 32 with a block-aligned stream offset: each lane of fused_infer_kernel draws its own B fragments
+    (one Philox block per lane and k-block; Z = 24 / 32 take a second k-block, Z = 4 / 12 leave quads of the first one
+    empty).  Rows against the oracle's decode of the same Philox elements, at a row count with a ragged last 16-row block,
+    and against the same rows drawn by the separate Philox launch (an unaligned offset one element further on)."""
+    rs = np.random.RandomState(Z)
+    D, hidden = 48, [96]
+    o = _oracle(D, hidden, Z, seed=31, rs=rs)
+    h = _handle(D, hidden, Z, seed=31, max_batch=16)
+    h.set_params(flatten_params(o.params))
+    n, off = 1000 + 7, 4 * 123
+    got = h.generate(n, philox_offset=off, loc=-0.25, scale=1.25)
+    z = -0.25 + 1.25 * philox_normal(31, STREAM_GENERATE, 0, off, n * Z).reshape(n, Z)
+    _close(got, o.decode(z), "in-kernel draw, Z = %d" % Z)
+    shifted = h.generate(n, philox_offset=off + 1, loc=-0.25, scale=1.25)          # separate draw (offset not block-aligned)
+    z1 = -0.25 + 1.25 * philox_normal(31, STREAM_GENERATE, 0, off + 1, n * Z).reshape(n, Z)
+    _close(shifted, o.decode(z1), "separate draw, Z = %d" % Z)
+    h.close()
+
+
 @pytest.mark.parametrize("D,hidden,Z,act,drop", [
     (64, [128], 16, "sigmoid", 1.0),        # the bench net N2: whole 16-byte row stores
     (67, [45, 130], 9, "tanh", 1.0),        # odd widths: element-wise stores, two encoder / three decoder layers
