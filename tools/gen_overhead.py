@@ -1,5 +1,6 @@
+"""Where a generate call of the bench net goes: Python wrapper, C call, launch + completion, kernel (run on the GPU box)."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from smrt_amd import _hip
 h = _hip.VaeHandle(n_features=64, hidden=[128], n_latent=16, activation="sigmoid", optimizer="rms_prop",
