@@ -172,6 +172,17 @@ enum { SMRT_PK_DROPOUT = 0, SMRT_PK_FWD, SMRT_PK_FWD_BCE, SMRT_PK_REPARAM, SMRT_
 int  smrt_vae_profile_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n_rows, int32_t batch_size,
                              int32_t n_epochs, double* ms_by_kind, int64_t* launches_by_kind);
 
+/* Host-side draws on numpy's LEGACY RandomState stream, bit for bit (smrt_amd/csrc/host_rng.cpp).  They replace the two
+ * sequential numpy loops that are the wall-clock of smrt_balance once the VAE trains on the GPU behind them:
+ *   smrt_rng_normal      = random_state.normal(loc, scale, size)   the latent draws of generate / generate_from_sample
+ *                          (smrt/autoencode/autoencoder.py:549-572, called per class from smrt/balance/smrt.py:226-238)
+ *   smrt_rng_permutation = random_state.permutation(np.arange(n))  the output shuffle (smrt/balance/smrt.py:244)
+ * State in / out in RandomState.get_state(legacy=True) form: key[624] (uint32), pos in [0, 624], has_gauss, cached_gauss.
+ * All pointers are HOST memory.  Returns 0, or -1 on a bad argument (state untouched). */
+int  smrt_rng_normal(uint32_t* key, int32_t* pos, int32_t* has_gauss, double* cached_gauss, double loc, double scale,
+                     double* out, int64_t n, int32_t n_threads);
+int  smrt_rng_permutation(uint32_t* key, int32_t* pos, int64_t* out, int64_t n);
+
 /* Host-side output assembly of smrt_balance: replaces the reference's X.copy() + per-class np.vstack + shuffle gather
  * (smrt/balance/smrt.py:184,237,244-250) with ONE multi-threaded pass.  All pointers are HOST memory.
  *   out[i][:] = fp64( row order[i] of the virtual concatenation [X (n_orig rows) ; synth (n_synth fp32 rows)] )

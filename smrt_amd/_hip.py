@@ -28,7 +28,7 @@ EXPORTS = [
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_generate_noalloc", "smrt_vae_generate_noalloc_max_rows", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
-    "smrt_assemble_rows", "smrt_assemble_rows_part", "smrt_assemble_rows_f64", "smrt_all_finite", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_mfma_peak_16x16x4", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
+    "smrt_assemble_rows", "smrt_assemble_rows_part", "smrt_assemble_rows_f64", "smrt_all_finite", "smrt_rng_normal", "smrt_rng_permutation", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_mfma_peak_16x16x4", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
     "smrt_last_error", "smrt_version",
 ]
 
@@ -107,6 +107,8 @@ def load():
     lib.smrt_assemble_rows_f64.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32]
     lib.smrt_all_finite.argtypes = [vp, i32, i64, i32]
     lib.smrt_assemble_rows_part.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32, i32]
+    lib.smrt_rng_normal.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_double), C.c_double, C.c_double, vp, i64, i32]
+    lib.smrt_rng_permutation.argtypes = [vp, C.POINTER(i32), vp, i64]
     _lib = lib
     return lib
 
@@ -226,6 +228,52 @@ def all_finite(X, n_threads=None):
     if rc < 0:
         raise HipLibraryError("smrt_all_finite rejected its arguments")
     return rc == 1
+
+
+# ---- draws on numpy's legacy stream (host_rng.cpp): same numbers, same state afterwards, a fraction of the time
+_RNG_MIN = 4096          # below this many values numpy's own loop is as fast as the round trip through get/set_state
+
+
+def _legacy_state(rs):
+    kind, key, pos, has_gauss, cached = rs.get_state(legacy=True)
+    if kind != "MT19937":
+        raise HipLibraryError("not a Mersenne-Twister RandomState")
+    return np.ascontiguousarray(key, dtype=np.uint32).copy(), C.c_int32(int(pos)), C.c_int32(int(has_gauss)), C.c_double(float(cached))
+
+
+def rng_normal(rs, size, loc=0.0, scale=1.0, n_threads=None):
+    """``rs.normal(loc, scale, size)`` for a ``numpy.random.RandomState`` -- the same fp64 values bit for bit and the same
+    generator state afterwards (the Mersenne-Twister pass stays sequential, the polar method's log / sqrt run on a thread
+    pool).  Scalar ``loc`` / ``scale`` only; anything else, and small draws, go to numpy itself."""
+    shape = (size,) if isinstance(size, (int, np.integer)) else tuple(size)
+    n = int(np.prod(shape, dtype=np.int64)) if len(shape) else 1
+    if (n < _RNG_MIN or not isinstance(rs, np.random.RandomState) or not np.isscalar(loc) or not np.isscalar(scale)
+            or not np.isfinite(scale) or scale < 0):
+        return rs.normal(loc, scale, size)
+    key, pos, has, cached = _legacy_state(rs)
+    out = np.empty(n, dtype=np.float64)
+    if n_threads is None:
+        n_threads = max(1, min(16, os.cpu_count() or 1))
+    rc = load().smrt_rng_normal(key.ctypes.data, C.byref(pos), C.byref(has), C.byref(cached), float(loc), float(scale),
+                                out.ctypes.data, n, int(n_threads))
+    if rc != 0:
+        raise HipLibraryError("smrt_rng_normal rejected its arguments (%d)" % rc)
+    rs.set_state(("MT19937", key, int(pos.value), int(has.value), float(cached.value)))
+    return out.reshape(shape)
+
+
+def rng_permutation(rs, n):
+    """``rs.permutation(np.arange(n))`` (int64) for a ``numpy.random.RandomState``, bit for bit, same state afterwards."""
+    n = int(n)
+    if n < _RNG_MIN or not isinstance(rs, np.random.RandomState):
+        return rs.permutation(np.arange(n))
+    key, pos, has, cached = _legacy_state(rs)
+    out = np.empty(n, dtype=np.int64)
+    rc = load().smrt_rng_permutation(key.ctypes.data, C.byref(pos), out.ctypes.data, n)
+    if rc != 0:
+        raise HipLibraryError("smrt_rng_permutation rejected its arguments (%d)" % rc)
+    rs.set_state(("MT19937", key, int(pos.value), int(has.value), float(cached.value)))     # (a shuffle leaves the kept normal alone)
+    return out
 
 
 class SplitAssembly(object):

@@ -318,12 +318,12 @@ class VariationalAutoEncoder(BaseEstimator, TransformerMixin):
         check_is_fitted(self, "topography_")
         X = check_array(X, dtype=NPDTYPE, ensure_2d=True, accept_sparse=False)
         z_mu, log_sigma = self.encode(X)
-        eps = self.random_state_.state.normal(size=log_sigma.shape, **nrm_args)
+        eps = _hip.rng_normal(self.random_state_.state, log_sigma.shape, **nrm_args)         # numpy's legacy stream, bit for bit
         z_mu += eps * np.exp(log_sigma)           # fp64 product stored into the fp32 array, as the reference
         return self.feed_forward(z_mu)
 
     def generate(self, n=1, **nrm_args):
         """Decode ``n`` draws ``z ~ N(loc, scale)`` from ``random_state_`` (autoencoder.py:549-572)."""
         check_is_fitted(self, "topography_")
-        z = self.random_state_.state.normal(size=(n, self.n_latent_factors), **nrm_args)
+        z = _hip.rng_normal(self.random_state_.state, (n, self.n_latent_factors), **nrm_args)
         return self.feed_forward(z)

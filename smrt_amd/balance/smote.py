@@ -139,7 +139,7 @@ def smote_balance(X, y, return_estimators=False, balance_ratio=0.2, strategy='pe
     synth = np.vstack(pieces) if pieces else None
     y_out = present_classes[np.concatenate([y_codes] + piece_codes)]
     n_total = y_out.shape[0]
-    output_order = random_state.permutation(np.arange(n_total)) if shuffle else None
+    output_order = _hip.rng_permutation(random_state, n_total) if shuffle else None          # == permutation(np.arange(n_total))
     X_out = _hip.assemble_rows(X, synth, output_order, synth_dtype=np.float64)
     if shuffle:
         y_out = y_out[output_order]

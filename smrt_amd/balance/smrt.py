@@ -219,7 +219,7 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
                 if gen_from_samples:
                     sample_idcs = random_state.choice(np.arange(n_sub), size=need, replace=True)
                 z_dim = resolve_latent(n_latent_factors, n_features)
-                noise = random_state.normal(size=(need, z_dim), **generate_args)
+                noise = _hip.rng_normal(random_state, (need, z_dim), **generate_args)     # == random_state.normal(...), bit for bit
                 if not mine:
                     noise = sample_idcs = None
             elif mine:
@@ -236,12 +236,12 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
                 if gen_from_samples:
                     random_state.choice(np.arange(n_sub), size=need, replace=True)
                 if getattr(encoder, "random_state_", None) is seeded_random_state:
-                    random_state.normal(size=(need, int(encoder.n_latent_factors)), **generate_args)
+                    _hip.rng_normal(random_state, (need, int(encoder.n_latent_factors)), **generate_args)
             drawn.append((noise, sample_idcs))
             blocks.append((cursor, need, owners[j], mine))
             y_out_codes[n_orig + cursor:n_orig + cursor + need] = code
             cursor += need
-        output_order = random_state.permutation(np.arange(n_total)) if shuffle else None
+        output_order = _hip.rng_permutation(random_state, n_total) if shuffle else None     # == permutation(np.arange(n_total))
         lap("draws")
         # the rows that come from X are written now, while the GPU is still training (85 % of the output on C2)
         assembly = _hip.SplitAssembly(X, n_synth, output_order)
