@@ -234,7 +234,9 @@ class VariationalAutoEncoder(BaseEstimator, TransformerMixin):
 
     def _prepare_fit(self, X):
         """Everything of ``fit`` in front of the training loop: validation, topography, session, initial weights."""
-        X = check_array(X, accept_sparse=False, ensure_2d=True, dtype=NPDTYPE)
+        # fp32 rows stay fp32: the reference converts to fp64 here (base.py:174) and feeds the graph fp32 -- a lossless round
+        # trip, but 8 x 31 MB of copies under the GIL when smrt_balance prepares C3's classes side by side
+        X = check_array(X, accept_sparse=False, ensure_2d=True, dtype=[NPDTYPE, np.float32])
         seeded_random_state = get_random_state(self.random_state)
         n_samples, n_features = X.shape
 
