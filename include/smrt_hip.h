@@ -114,6 +114,24 @@ int  smrt_vae_train_epochs_multi(smrt_vae** hs, int32_t n_handles, const float* 
                                  const int64_t* n_rows, int32_t batch_size, int32_t n_epochs,
                                  float* epoch_cost_host, float* epoch_ms_host);
 
+/* Which training path a handle takes (no counterpart in the reference: its one path is Session.run per mini-batch,
+ * base.py:215-217).  Nets whose weights fit one CU's LDS train an epoch in ONE persistent launch whose workgroups must all
+ * be resident at once; a device holds smrt_persistent_budget(device) of them per process (5/8 of its CUs, divided by
+ * LOCAL_WORLD_SIZE / visible devices when several ranks share a GPU; SMRT_HIP_PERSIST_BUDGET overrides).
+ *   smrt_vae_persistent_workgroups: workgroups such a launch of h would hold at mini-batches of batch_rows rows; 0 when h
+ *                                   or the schedule does not qualify.
+ *   smrt_vae_set_persistent       : mode -1 (default) -- taken when the workgroups fit what is left of the budget at the
+ *                                   moment of the call (first come, first served between concurrent calls);
+ *                                   0 -- never (always the two-launch step); 1 -- always: the caller has planned the
+ *                                   budget over its handles itself, so that which of several concurrent fits take this
+ *                                   path does not depend on thread timing (smrt_amd/autoencode/vae.py: fit_group).
+ * A persistent launch that cannot become co-resident gives up after 2 s; smrt_vae_train_epochs then runs that epoch and
+ * the ones after it again on the two-launch step (weights and slots are intact), unless SMRT_HIP_PERSIST_NO_FALLBACK=1,
+ * in which case it returns -6. */
+int32_t smrt_persistent_budget(int32_t device);
+int32_t smrt_vae_persistent_workgroups(const smrt_vae* h, int32_t batch_rows);
+int  smrt_vae_set_persistent(smrt_vae* h, int32_t mode);
+
 /* Data-parallel halves of a step (no reference counterpart): grad_step leaves
  * [internal-layout gradient sums | sum of row losses] scaled by 1/global_rows in grads_dev
  * (smrt_vae_dp_count floats) so ranks can all-reduce(SUM) it; apply_grads adds L2, clips, updates.
@@ -150,8 +168,11 @@ int  smrt_vae_generate(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc
  * path, the decoder's two ping-pong activation buffers -- live in a static device array of
  * SMRT_NOALLOC_SCRATCH_BYTES per GPU instead of library-allocated buffers.  No hipMalloc / hipFree / allocating
  * routine is called.  n may not exceed smrt_vae_generate_noalloc_max_rows(h) (= scratch floats / (rup4(Z) [+ 2 x widest
- * layer])); a larger n returns -5 with a message and writes nothing.  Every call on a GPU shares that GPU's array:
- * calls that overlap on one GPU (other handles, other threads) race; the array is cleared at the start of each call. */
+ * layer])); a larger n returns -5 with a message and writes nothing.  Every call on a GPU shares that GPU's array: the
+ * calls of one PROCESS take turns on it (a per-device mutex, held until the call's stream has drained); calls from
+ * different processes on one GPU each have their own copy.  The array is cleared at the start of each call that uses it;
+ * where smrt_vae_generate draws z inside its decode launch (LDS-resident nets, Z % 4 == 0, Z <= 32, philox_offset % 4 ==
+ * 0) so does this call, and the array is not touched. */
 #define SMRT_NOALLOC_SCRATCH_BYTES (8 << 20)
 int64_t smrt_vae_generate_noalloc_max_rows(const smrt_vae* h);
 int  smrt_vae_generate_noalloc(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc, float scale,

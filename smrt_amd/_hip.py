@@ -24,7 +24,7 @@ EXPORTS = [
     "smrt_vae_create", "smrt_vae_destroy", "smrt_vae_param_count", "smrt_vae_set_params",
     "smrt_vae_get_params", "smrt_vae_get_opt_state", "smrt_vae_reset_opt_state", "smrt_vae_step_count",
     "smrt_vae_set_dropout_masks", "smrt_vae_train_step", "smrt_vae_train_epochs", "smrt_vae_train_epochs_multi",
-    "smrt_vae_dp_count",
+    "smrt_vae_dp_count", "smrt_persistent_budget", "smrt_vae_persistent_workgroups", "smrt_vae_set_persistent",
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_generate_noalloc", "smrt_vae_generate_noalloc_max_rows", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
@@ -91,6 +91,9 @@ def load():
     lib.smrt_vae_train_epochs.argtypes = [vp, vp, i64, i64, i32, i32, i32, C.c_float, f32p, f32p, C.POINTER(i32)]
     lib.smrt_vae_train_epochs_multi.argtypes = [C.POINTER(vp), i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), i32, i32,
                                                 f32p, f32p]
+    lib.smrt_persistent_budget.argtypes = [i32]; lib.smrt_persistent_budget.restype = i32
+    lib.smrt_vae_persistent_workgroups.argtypes = [vp, i32]; lib.smrt_vae_persistent_workgroups.restype = i32
+    lib.smrt_vae_set_persistent.argtypes = [vp, i32]
     lib.smrt_vae_grad_step.argtypes = [vp, vp, i64, i32, i64, i64, vp, vp]
     lib.smrt_vae_apply_grads.argtypes = [vp, vp, f32p]
     lib.smrt_vae_grad_step_async.argtypes = [vp, vp, i64, i32, i64, i64, vp, vp]
@@ -372,6 +375,11 @@ def smote_rows(X_dev, base_idx, nbr_idx, r, mode="perturb", to_host=True):
     return out.cpu().numpy() if to_host else out
 
 
+def persistent_budget(device=0):
+    """Persistent workgroups this process may keep resident on ``device`` (include/smrt_hip.h)."""
+    return int(load().smrt_persistent_budget(int(device)))
+
+
 def train_epochs_multi(handles, Xs, batch_size, n_epochs):
     """The ``_train`` loops of several handles side by side with grouped launches (``smrt_vae_train_epochs_multi``).
 
@@ -530,6 +538,14 @@ class VaeHandle(object):
         _check(self._lib.smrt_vae_profile_epochs(self._live(), Xt.data_ptr(), ldx, Xt.shape[0], int(batch_size),
                                                  int(n_epochs), ms, cnt), "smrt_vae_profile_epochs")
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}
+
+    def persistent_workgroups(self, batch_rows):
+        """Workgroups one persistent whole-epoch launch of this handle holds (0: the net or the schedule does not qualify)."""
+        return int(self._lib.smrt_vae_persistent_workgroups(self._live(), int(batch_rows)))
+
+    def set_persistent(self, mode):
+        """-1: persistent path when the device's budget has room at call time; 0: never; 1: always (budget planned by the caller)."""
+        _check(self._lib.smrt_vae_set_persistent(self._live(), int(mode)), "smrt_vae_set_persistent")
 
     @property
     def last_epoch_launches(self):

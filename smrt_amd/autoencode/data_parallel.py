@@ -83,6 +83,11 @@ class DataParallelTrainer(object):
         # memset all take h->stream), so the wait was inside gloo's own device-tensor path (its worker thread's private
         # stream against the legacy stream), which this loop no longer enters.  RCCL is ordered on the stream itself.
         self.host_collective = bool(self.on_gpu and dist is not None and self.world > 1 and dist.get_backend() != "nccl")
+        # measurement aid (bench.py: dp_c4): with `time_collective` set, every RCCL all-reduce is bracketed by a pair of
+        # events on the stream it is ordered on (no host wait); `collective_ms` then holds the per-step device times of
+        # the most recent run_epochs call.  Nothing overlaps the collective in this loop, so all of it is exposed.
+        self.time_collective = False
+        self.collective_ms = []
 
     def run_epochs(self, n_epochs, early_stopping=False, min_change=1e-3):
         """Returns ``(costs, seconds)`` per finished epoch (cost of the last batch, base.py:222)."""
@@ -92,6 +97,7 @@ class DataParallelTrainer(object):
         costs, seconds, last = [], [], None
         stream = torch.cuda.current_stream(sess.device) if self.on_gpu else None
         sess.use_stream(stream)
+        timed = []
         try:
             for ep in range(int(n_epochs)):
                 if self.on_gpu:
@@ -107,6 +113,12 @@ class DataParallelTrainer(object):
                             g_host = self.grads.cpu()
                             dist.all_reduce(g_host)
                             self.grads.copy_(g_host)
+                        elif self.time_collective and self.on_gpu:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record(stream)
+                            dist.all_reduce(self.grads)
+                            e1.record(stream)
+                            timed.append((e0, e1))
                         else:
                             dist.all_reduce(self.grads)                # SUM; RCCL ring / tree over xGMI under nccl
                     sess.dp_apply(self.grads, cost[ep:ep + 1] if i == len(self.plan) - 1 else None)
@@ -129,4 +141,7 @@ class DataParallelTrainer(object):
                         last = c
         finally:
             sess.use_stream(None)
+        if timed:
+            torch.cuda.synchronize(sess.device)
+            self.collective_ms = [e0.elapsed_time(e1) for e0, e1 in timed]
         return np.asarray(costs, dtype=np.float32), seconds

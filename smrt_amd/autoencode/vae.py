@@ -62,11 +62,39 @@ def fit_group(estimators, Xs, n_threads=8):
             "declined" if res is None else "grouped, %d epochs of %.3f ms on the device" % (len(res[1]), float(np.mean(res[1])))))
     if res is None:
         # declined (LDS-resident nets, big batches): every handle trains alone, side by side on its own stream and host
-        # thread (ctypes releases the GIL)
+        # thread (ctypes releases the GIL).  The persistent whole-epoch launch and the two-launch step agree to 2e-5 only,
+        # and a fixed random_state must give a fixed result whatever the thread timing, the number of classes or the
+        # number of ranks: so EVERY class whose net qualifies takes the persistent launch, and the device's budget of
+        # co-resident workgroups only decides how many of them run at the same time (they start in class order; a class
+        # waits for room instead of changing its path).  Only a class that alone exceeds the budget keeps the other step.
+        import threading
+        budget = _hip.persistent_budget(estimators[0].sess.device.index or 0)
+        needs = []
+        for e, p in zip(estimators, prepared):
+            need = e.sess.persistent_workgroups(min(int(p[2]), int(p[0].shape[0])))
+            grant = 0 < need <= budget
+            e.sess.set_persistent(1 if grant else 0)
+            needs.append(need if grant else 0)
+        room = threading.Condition()
+        state = {"free": budget, "turn": 0}
+
+        def train(k):
+            est, X_dev, prep = estimators[k], X_devs[k], prepared[k]
+            with room:                           # start in class order, when the workgroups fit beside the running ones
+                room.wait_for(lambda: state["turn"] == k and state["free"] >= needs[k])
+                state["free"] -= needs[k]
+                state["turn"] += 1
+                room.notify_all()
+            try:
+                return est.sess.train_epochs(X_dev, prep[2], est.n_epochs)
+            finally:
+                with room:
+                    state["free"] += needs[k]
+                    room.notify_all()
+
         from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=max(1, min(int(n_threads), len(estimators)))) as pool:
-            each = list(pool.map(lambda ex: ex[0].sess.train_epochs(ex[1], ex[2][2], ex[0].n_epochs),
-                                 zip(estimators, X_devs, prepared)))
+        with ThreadPoolExecutor(max_workers=len(estimators)) as pool:
+            each = list(pool.map(train, range(len(estimators))))
     else:
         each = [(res[0][k], res[1]) for k in range(len(estimators))]
     for e, p, (costs, ms) in zip(estimators, prepared, each):

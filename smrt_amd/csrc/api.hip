@@ -80,6 +80,7 @@ struct smrt_vae {
     int n_l2 = 0;
     float* cost_dev = nullptr; long cost_cap = 0;
     float* cost_pin = nullptr; long cost_pin_cap = 0;
+    unsigned* err_pin = nullptr;         // per-epoch copies of the persistent kernel's error word (same capacity as cost_pin)
 
     long icap = 0, izcap = 0;
     float* ibuf[2] = {nullptr, nullptr};
@@ -93,6 +94,7 @@ struct smrt_vae {
     // cached epoch graph (valid while X, the schedule and the workspace pointers are unchanged)
     hipGraph_t graph = nullptr; hipGraphExec_t gexec = nullptr;
     const float* g_X = nullptr; long g_ldx = 0, g_n = 0, g_batch = 0;
+    int g_launches = 0;                  // kernel nodes of the cached epoch graph
 
     // row-tile fused forward/backward (small nets): LDS plan
     bool fused = false;
@@ -107,7 +109,8 @@ struct smrt_vae {
     // persistent whole-epoch kernel (persist_train.hip)
     bool persist_ok = false;         // the net qualifies (fits in LDS, no dropout, VAE)
     unsigned* pcnt = nullptr;        // producer flags + error word (256 words)
-    int persist_wgs_held = 0;        // workgroups reserved in the process-wide budget while a call runs
+    int persist_mode = -1;           // -1: first come, first served inside the device's budget; 0: never; 1: the caller
+                                     //     has planned the budget itself (smrt_vae_set_persistent): always granted
 
     // per-kernel profiling (eager launches bracketed by events)
     bool prof = false;
@@ -261,14 +264,38 @@ static void plan_fused(smrt_vae* h) {
 }
 
 // Workgroups of the persistent kernel for a mini-batch size; 0: this schedule does not take the persistent path.
-// One compute workgroup per 16 rows (+ one owner wave per weight-gradient tile, persist_owner_workgroups).  Co-residency of the whole grid is what its counters rely on: all persistent launches of
-// the process together are kept to PERSIST_WG_BUDGET of the 256 CUs (one workgroup per CU: LDS), the rest take the
-// two-kernel step.
+// One compute workgroup per 16 rows (+ one owner wave per weight-gradient tile, persist_owner_workgroups).  Co-residency
+// of the whole grid is what its flags rely on: all persistent launches of the process on one device together are kept
+// to persist_budget(device) workgroups (one workgroup per CU: LDS), the rest take the two-kernel step.
 constexpr int PERSIST_ROWS_MAX = 512;
-constexpr int PERSIST_WG_BUDGET = 160;
-static std::atomic<int> g_persist_wgs{0};
+constexpr int SMRT_MAX_DEVICES = 64;
+static std::atomic<int> g_persist_wgs[SMRT_MAX_DEVICES];
+// Co-resident persistent workgroups a process may hold on one device: 5/8 of the device's CUs (160 of 256; the rest stays
+// free for the other streams' kernels), divided by the number of processes that share the GPU when a launcher says so
+// (LOCAL_WORLD_SIZE ranks over fewer visible devices: bench.py's one-GPU rehearsal of the multi-rank paths), or
+// SMRT_HIP_PERSIST_BUDGET.  A grid that would not be co-resident deadlocks its flag waits (bounded: 2 s, then -6 and the
+// two-launch fallback), so the figure errs low.
+static int persist_budget(int device) {
+    static int cached[SMRT_MAX_DEVICES];
+    static std::once_flag once[SMRT_MAX_DEVICES];
+    if (device < 0 || device >= SMRT_MAX_DEVICES) return 0;
+    std::call_once(once[device], [device]() {
+        int cus = 256, ndev = 1;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        (void)hipGetDeviceCount(&ndev);
+        int budget = cus * 5 / 8;
+        const char* lws = std::getenv("LOCAL_WORLD_SIZE");
+        const int ranks = lws ? std::max(1, std::atoi(lws)) : 1;
+        const int share = (ranks + std::max(ndev, 1) - 1) / std::max(ndev, 1);        // ranks per visible GPU
+        budget /= std::max(share, 1);
+        cached[device] = budget;
+    });
+    const char* e = std::getenv("SMRT_HIP_PERSIST_BUDGET");          // (read per call: tests vary it)
+    return (e && *e) ? std::max(0, std::atoi(e)) : cached[device];
+}
 static int persist_grid(const smrt_vae* h, long batch_rows) {
-    if (!h->persist_ok || batch_rows > PERSIST_ROWS_MAX || batch_rows < 1) return 0;
+    if (!h->persist_ok || h->persist_mode == 0 || batch_rows > PERSIST_ROWS_MAX || batch_rows < 1) return 0;
     return (int)((batch_rows + 15) / 16);
 }
 
@@ -500,7 +527,8 @@ static int build_stages(const smrt_vae* h, const FusedArgs& f, FusedStage* stage
 
 // One whole epoch (every contiguous mini-batch, ragged tail last) in ONE persistent launch + the cost of the last batch.
 // Returns the number of launches enqueued.
-static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_rows, int batch, int G, float* cost_slot) {
+static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_rows, int batch, int G, float* cost_slot,
+                                 bool inject_fault = false) {
     hipStream_t s = h->stream;
     const FusedArgs& f = h->fplan;
     PersistArgs a{};
@@ -518,8 +546,13 @@ static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_r
     a.opt = h->cfg.optimizer; a.clip = h->cfg.clip; a.has_l2 = h->has_l2 ? 1 : 0;
     a.lr = h->cfg.learning_rate; a.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
     a.gmin = h->cfg.gclip_min; a.gmax = h->cfg.gclip_max;
-    // counters and the error word start at zero for every launch (stream-ordered, no host wait)
-    if (hipMemsetAsync(h->pcnt, 0, 256 * sizeof(unsigned), s) != hipSuccess) return -1;
+    // The producer flags (words [0, 192)) start at zero for every launch (stream-ordered, no host wait).  The error word
+    // (192) is STICKY across the launches of one smrt_vae_train_epochs call: it is cleared once, at the start of the call,
+    // every workgroup reads it in its prologue and leaves at once when it is set -- an epoch that follows a timed-out one
+    // must not train on the half-updated image twin, and the host must still see the error after the last epoch.
+    if (hipMemsetAsync(h->pcnt, 0, 192 * sizeof(unsigned), s) != hipSuccess) return -1;
+    // test hook (SMRT_HIP_PERSIST_FAULT_EPOCH): raise the error word in front of this launch, as a peer's time-out would
+    if (inject_fault && hipMemsetAsync(h->pcnt + 192, 1, sizeof(unsigned), s) != hipSuccess) return -1;
 #ifdef SMRT_STAMPS
     static unsigned long long* pdbg = nullptr;
     if (!pdbg) { (void)hipMalloc((void**)&pdbg, 64 * 8); (void)hipMemset(pdbg, 0, 64 * 8); }
@@ -893,6 +926,7 @@ void smrt_vae_destroy(smrt_vae* h) {
     float* ibufs[] = {h->ibuf[0], h->ibuf[1], h->izb};
     for (float* b : ibufs) if (b) (void)hipFree(b);
     if (h->cost_pin) (void)hipHostFree(h->cost_pin);
+    if (h->err_pin) (void)hipHostFree(h->err_pin);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
     drop_graph(h);
@@ -904,6 +938,21 @@ int64_t smrt_vae_param_count(const smrt_vae* h) { return h ? h->P_abi : -1; }
 int64_t smrt_vae_dp_count(const smrt_vae* h) { return h ? h->P_int + 4 : -1; }
 int64_t smrt_vae_step_count(const smrt_vae* h) { return h ? h->steps : -1; }
 int smrt_vae_last_epoch_launches(const smrt_vae* h) { return h ? h->last_epoch_launches : -1; }
+
+int32_t smrt_persistent_budget(int32_t device) { return persist_budget(device); }
+int32_t smrt_vae_persistent_workgroups(const smrt_vae* h, int32_t batch_rows) {
+    if (!h) return -1;
+    if (!h->persist_ok || batch_rows > PERSIST_ROWS_MAX || batch_rows < 1) return 0;
+    const int owners = persist_owner_workgroups(h->tiles16);
+    if (owners > persist_max_owner_workgroups()) return 0;
+    return (batch_rows + 15) / 16 + owners;
+}
+int smrt_vae_set_persistent(smrt_vae* h, int32_t mode) {
+    if (!h) return fail(-1, "smrt_vae_set_persistent: null handle");
+    if (mode < -1 || mode > 1) return fail(-1, "smrt_vae_set_persistent: mode must be -1 (automatic), 0 (never) or 1 (planned by the caller)");
+    h->persist_mode = mode;
+    return 0;
+}
 
 int smrt_vae_set_params(smrt_vae* h, const float* host_flat, int64_t n) {
     if (!h || !host_flat) return fail(-1, "smrt_vae_set_params: null argument");
@@ -981,8 +1030,10 @@ int smrt_vae_set_dropout_masks(smrt_vae* h, const float* host_flat, int64_t n) {
 static int ensure_cost(smrt_vae* h, long n) {
     if (n > h->cost_pin_cap) {
         if (h->cost_pin) (void)hipHostFree(h->cost_pin);
-        h->cost_pin = nullptr;
+        if (h->err_pin) (void)hipHostFree(h->err_pin);
+        h->cost_pin = nullptr; h->err_pin = nullptr; h->cost_pin_cap = 0;
         HIPC(hipHostMalloc((void**)&h->cost_pin, sizeof(float) * n, hipHostMallocDefault));
+        HIPC(hipHostMalloc((void**)&h->err_pin, sizeof(unsigned) * n, hipHostMallocDefault));
         h->cost_pin_cap = n;
     }
     return 0;
@@ -1039,29 +1090,34 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     if (epochs_done) *epochs_done = 0;
     if (n_epochs == 0) return 0;
     ensure_image(h);
-    // The persistent whole-epoch kernel when the net and the schedule qualify and its workgroups fit the process-wide
-    // budget of co-resident persistent workgroups (released when this call returns, whichever way).
+    // The persistent whole-epoch kernel when the net and the schedule qualify and its workgroups fit the device's budget of
+    // co-resident persistent workgroups (released when this call returns, whichever way).  A caller that has planned the
+    // budget over several handles itself (smrt_vae_set_persistent(h, 1): fit_group, in class order, so that which classes
+    // take this path does not depend on thread timing) is always granted.
     int PG = persist_grid(h, bmax);
     if (PG && persist_owner_workgroups(h->tiles16) > persist_max_owner_workgroups()) PG = 0;
     const int PW = PG ? PG + persist_owner_workgroups(h->tiles16) : 0;          // workgroups of the launch
+    std::atomic<int>& held = g_persist_wgs[std::min(std::max(h->device, 0), SMRT_MAX_DEVICES - 1)];
     if (PG) {
-        const int prev = g_persist_wgs.fetch_add(PW);
-        if (prev + PW > PERSIST_WG_BUDGET) { g_persist_wgs.fetch_sub(PW); PG = 0; }
+        const int prev = held.fetch_add(PW);
+        if (h->persist_mode != 1 && prev + PW > persist_budget(h->device)) { held.fetch_sub(PW); PG = 0; }
     }
-    struct Release { int n; ~Release() { if (n) g_persist_wgs.fetch_sub(n); } } release{PG ? PW : 0};
-    auto persist_failed = [&]() -> bool {
-        if (!PG) return false;
-        unsigned e = 0;
-        if (hipMemcpy(&e, h->pcnt + 192, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return true;
-        return e != 0;
-    };
+    struct Release { std::atomic<int>* c; int n; void drop() { if (n) c->fetch_sub(n); n = 0; } ~Release() { drop(); } } release{&held, PG ? PW : 0};
+    // test hooks: SMRT_HIP_PERSIST_FAULT_EPOCH = e raises the error word in front of epoch e's launch (what a peer's time-out
+    // leaves behind); SMRT_HIP_PERSIST_NO_FALLBACK = 1 reports it (-6) instead of re-running on the two-launch step
+    const char* fe_env = std::getenv("SMRT_HIP_PERSIST_FAULT_EPOCH");
+    const int fault_epoch = (fe_env && *fe_env) ? std::atoi(fe_env) : -1;
+    const char* nf_env = std::getenv("SMRT_HIP_PERSIST_NO_FALLBACK");
+    const bool no_fallback = nf_env && std::atoi(nf_env) != 0;
+    if (PG) HIPC(hipMemsetAsync(h->pcnt + 192, 0, 64 * sizeof(unsigned), h->stream));      // the sticky error word: once per call
+    int cur_epoch = 0;
 
     // Enqueue one epoch (every contiguous batch, ragged tail last: sklearn gen_batches, base.py:198-199).
     // The cost of the LAST batch lands in `slot` (base.py:222); other steps write a scratch slot.
     auto enqueue_epoch = [&](float* slot) -> int {
         int launches = 0;
         if (PG) {
-            launches = enqueue_persist_epoch(h, X_dev, ldx, n_rows, batch_size, PG, slot);
+            launches = enqueue_persist_epoch(h, X_dev, ldx, n_rows, batch_size, PG, slot, cur_epoch == fault_epoch);
             if (launches < 0) return fail(-2, "persistent epoch: counter reset failed");
             h->last_epoch_launches = launches;
             return 0;
@@ -1082,7 +1138,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     bool graphed = false;
     if (h->use_graph && !PG && !h->prof && n_epochs > 1 && h->stream == h->own_stream) {
         const bool hit = h->gexec && h->g_X == X_dev && h->g_ldx == ldx && h->g_n == n_rows && h->g_batch == batch_size;
-        if (hit) graphed = true;
+        if (hit) { graphed = true; h->last_epoch_launches = h->g_launches; }
         else {
             drop_graph(h);
             // Build the epoch graph node by node (vae_kernels.hpp: GraphBuild) -- no stream is ever put into capture.
@@ -1097,6 +1153,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
                     hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0) == hipSuccess) {
                     graphed = true;
                     h->g_X = X_dev; h->g_ldx = ldx; h->g_n = n_rows; h->g_batch = batch_size;
+                    h->g_launches = h->last_epoch_launches;
                 } else {
                     (void)hipGetLastError(); drop_graph(h);
                     if (rc) return rc;
@@ -1111,19 +1168,49 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
             harvest(ep);
         }
         const int k = ep % EV_RING;
+        cur_epoch = ep;
         HIPC(hipEventRecord(h->events[2 * k], h->stream));
         if (graphed) HIPC(hipGraphLaunch(h->gexec, h->stream));
         else TRY(enqueue_epoch(h->cost_dev));
         HIPC(hipEventRecord(h->events[2 * k + 1], h->stream));
         HIPC(hipMemcpyAsync(h->cost_pin + ep, h->cost_dev, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        if (PG) HIPC(hipMemcpyAsync(h->err_pin + ep, h->pcnt + 192, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
         return 0;
     };
+    // A persistent launch whose workgroups gave up waiting for a peer (2 s: the grid was not co-resident -- another process
+    // on the GPU, a CU mask) leaves the flat W / slot buffers and the step scalars exactly as they were when ITS epoch
+    // began: owners write them back only at the end of a complete launch, and every later launch of this call leaves in
+    // its prologue (sticky error word).  So the first epoch whose error word is set, and all after it, are simply run
+    // again on the two-launch step; only the image twin has to be rebuilt from W.
+    auto first_failed = [&](int from, int upto) -> int {
+        if (!PG) return -1;
+        for (int ep = from; ep < upto; ++ep) if (h->err_pin[ep] != 0u) return ep;
+        return -1;
+    };
+    auto leave_persistent = [&]() -> int {
+        PG = 0; release.drop();
+        h->img_valid = false;
+        ensure_image(h);
+        HIPC(hipMemsetAsync(h->pcnt + 192, 0, 64 * sizeof(unsigned), h->stream));
+        return 0;
+    };
+    const char* give_up = "smrt_vae_train_epochs: the persistent training kernel gave up waiting for a peer workgroup (2 s) and "
+                          "SMRT_HIP_PERSIST_NO_FALLBACK is set; weights, slots and step count are those at the start of the failed epoch";
     if (!early_stopping) {
-        for (int ep = 0; ep < n_epochs && rc == 0; ++ep) rc = run_epoch(ep);
-        if (rc) return rc;
-        hipError_t e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e));
-        if (persist_failed()) return fail(-6, "smrt_vae_train_epochs: the persistent training kernel gave up waiting for a peer workgroup (2 s); the handle's parameters are undefined");
+        int ep0 = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            for (int ep = ep0; ep < n_epochs && rc == 0; ++ep) rc = run_epoch(ep);
+            if (rc) return rc;
+            hipError_t e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e));
+            const int bad = first_failed(ep0, n_epochs);
+            if (bad < 0) break;
+            if (no_fallback) { h->steps += (int64_t)bad * nb; h->img_valid = false; return fail(-6, give_up); }
+            harvest(bad);
+            harvested = std::min(harvested, bad);          // the epochs from `bad` on are timed again
+            TRY(leave_persistent());
+            ep0 = bad;
+        }
         done = n_epochs;
     } else {
         for (int ep = 0; ep < n_epochs; ++ep) {
@@ -1131,7 +1218,15 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
             if (rc) return rc;
             hipError_t e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e));
-            if (persist_failed()) return fail(-6, "smrt_vae_train_epochs: the persistent training kernel gave up waiting for a peer workgroup (2 s); the handle's parameters are undefined");
+            if (first_failed(ep, ep + 1) >= 0) {
+                if (no_fallback) { h->steps += (int64_t)ep * nb; h->img_valid = false; return fail(-6, give_up); }
+                harvest(ep);
+                TRY(leave_persistent());
+                rc = run_epoch(ep);
+                if (rc) return rc;
+                e = hipStreamSynchronize(h->stream);
+                if (e != hipSuccess) return fail(-2, std::string("train_epochs sync: ") + hipGetErrorString(e));
+            }
             done = ep + 1;
             const float c = h->cost_pin[ep];
             if (!have_last) { last_cost = c; have_last = true; }
@@ -1162,7 +1257,8 @@ int smrt_vae_train_epochs_multi(smrt_vae** hs, int32_t n_handles, const float* c
         if (!h) return fail(-1, "smrt_vae_train_epochs_multi: null handle");
         if (n_rows[k] < 1) return fail(-1, "smrt_vae_train_epochs_multi: bad sizes");
         TRY(check_mat(X_dev[k], ldx[k], h->D, "smrt_vae_train_epochs_multi: X"));
-        if (h->device != hs[0]->device || h->fused || h->prof || std::min<int64_t>(batch_size, n_rows[k]) > SMALL_M_MAX)
+        if (h->device != hs[0]->device || h->fused || h->prof || std::min<int64_t>(batch_size, n_rows[k]) > SMALL_M_MAX ||
+            h->stream != h->own_stream)             // (a lent stream orders this handle against its lender's work, not ours)
             return 1;
         for (int j = 0; j < k; ++j) if (hs[j] == h) return fail(-1, "smrt_vae_train_epochs_multi: a handle appears twice");
     }
@@ -1285,6 +1381,16 @@ int smrt_vae_train_epochs_multi(smrt_vae** hs, int32_t n_handles, const float* c
             hs[k]->steps += (int64_t)n_epochs * ((n_rows[k] + batch_size - 1) / batch_size);
             hs[k]->last_epoch_launches = (int)plan.size();
         }
+    }
+    if (rc != 0) {
+        // launches may have run: the device-side step counters are the truth (an epoch advances them once per mini-batch)
+        (void)hipStreamSynchronize(stream);
+        for (int k = 0; k < n_handles; ++k) {
+            DevState st{};
+            if (hipMemcpy(&st, hs[k]->st, sizeof(st), hipMemcpyDeviceToHost) == hipSuccess) hs[k]->steps = (int64_t)st.step;
+            hs[k]->img_valid = false;
+        }
+        (void)hipGetLastError();
     }
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (gexec) (void)hipGraphExecDestroy(gexec);
@@ -1614,9 +1720,9 @@ int smrt_vae_generate(smrt_vae* h, int64_t n, uint64_t philox_offset, float loc,
 // uses that pointer.
 #define SMRT_NOALLOC_SCRATCH_FLOATS (SMRT_NOALLOC_SCRATCH_BYTES / 4)
 static __device__ __align__(256) __attribute__((used)) float scratch[SMRT_NOALLOC_SCRATCH_FLOATS];
-constexpr int SMRT_MAX_DEVICES = 64;
 static float* g_scratch_ptr[SMRT_MAX_DEVICES] = {nullptr};
 static std::mutex g_scratch_mu;
+static std::mutex g_noalloc_mu[SMRT_MAX_DEVICES];     // one call at a time per GPU: every call on a GPU shares that GPU's array
 
 // Address of this device's copy of `scratch` (resolved on first use, with `device` current).
 static int scratch_on(int device, float** out) {
@@ -1653,11 +1759,22 @@ int smrt_vae_generate_noalloc(smrt_vae* h, int64_t n, uint64_t philox_offset, fl
                         " rows this net can generate from the " + std::to_string(SMRT_NOALLOC_SCRATCH_BYTES >> 20) +
                         " MiB static scratch; use smrt_vae_generate or split the call");
     if (n == 0) return 0;
+    if (h->device < 0 || h->device >= SMRT_MAX_DEVICES) return fail(-1, "smrt_vae_generate_noalloc: device index out of range");
     HIPC(hipSetDevice(h->device));
+    const bool fused_ok = h->fused && h->Wimg && infer_fused_fits(h, h->dec0, h->NL - 1);
+    if (fused_ok) {
+        // where smrt_vae_generate draws z inside the persistent decode launch, so does this call: no latent buffer at all
+        // (infer_fused enqueues nothing and returns 0 when the in-kernel draw does not apply: ragged Z, unaligned offset)
+        const GenDraw gd{philox_offset, loc, scale};
+        const int f = infer_fused(h, h->dec0, h->NL - 1, nullptr, 0, n, out_dev, ldo, h->D, nullptr, 0, &gd);
+        if (f < 0) return f;
+        if (f) { HIPC(hipGetLastError()); HIPC(hipStreamSynchronize(h->stream)); return 0; }
+    }
+    // the calls of all handles and host threads on this GPU take turns on its array (held until the stream has drained)
+    std::lock_guard<std::mutex> turn(g_noalloc_mu[h->device]);
     float* sp = nullptr;
     TRY(scratch_on(h->device, &sp));
     const long ldz = rup4(h->Z);
-    const bool fused_ok = h->fused && h->Wimg && infer_fused_fits(h, h->dec0, h->NL - 1);
     // carve: [z : n x ldz] [activations A : n x maxld] [activations B : n x maxld], each piece 256-byte aligned by
     // construction (ldz and maxld are multiples of 4 floats; round the piece sizes up to 64 floats)
     const size_t zf = ((size_t)n * ldz + 63) & ~size_t(63);

@@ -15,6 +15,15 @@ __device__ __forceinline__ float fast_sigmoid(float v) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 
+// tf.maximum(t, lo) / tf.minimum(t, hi) as TF-1.x's CPU kernels evaluate them (Eigen scalar_max_op / scalar_min_op are
+// std::max / std::min: "(a < b) ? b : a" and "(b < a) ? b : a" with a = t): a NaN t STAYS NaN, where fmaxf / fminf would
+// return the bound.  tf.clip_by_value(t, lo, hi) = minimum(maximum(t, lo), hi) (_ae_utils.py:31, base.py:144) therefore
+// hands a NaN gradient on to the weights -- once p == 1.0f has produced inf * 0 in the output layer the
+// reference's parameters, costs and generated rows are NaN from then on, and so are ours (the oracle's np.clip agrees).
+__device__ __forceinline__ float tf_maximum(float t, float lo) { return (t < lo) ? lo : t; }
+__device__ __forceinline__ float tf_minimum(float t, float hi) { return (hi < t) ? hi : t; }
+__device__ __forceinline__ float tf_clip(float t, float lo, float hi) { return tf_minimum(tf_maximum(t, lo), hi); }
+
 // Forward activations (reference: smrt/autoencode/autoencoder.py:28-34 -> tf.nn.*).
 __device__ __forceinline__ float act_fwd(int act, float v) {
     switch (act) {

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(BTHREADS) void fused_dw_opt_kernel(const DwOptArgs 
     }
     if (a.clip) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) g[r] = fminf(fmaxf(g[r], a.gmin), a.gmax);
+        for (int r = 0; r < 4; ++r) g[r] = tf_clip(g[r], a.gmin, a.gmax);
     }
     opt_apply4(a.opt, a.lr, alpha, w, g, s0, s1, wn);
 #pragma unroll

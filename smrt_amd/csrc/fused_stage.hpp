@@ -225,7 +225,7 @@ __device__ __forceinline__ int run_stage(const int4 d0, const int4 d1, const int
                         const bool valid = (4 * q + r) < rows_here;
                         const float p = fast_sigmoid(v[r] + bcol);
                         const float x = xr[r * s_aux];
-                        const float pl = fmaxf(p, lo), pc = fminf(pl, hi), om = 1.0f - pc;
+                        const float pl = tf_maximum(p, lo), pc = tf_minimum(pl, hi), om = 1.0f - pc;
                         const float term = x * __logf(pc) + (1.0f - x) * __logf(om);
                         bce -= valid ? term : 0.0f;
                         // TF clip_by_value gradient gate: Maximum passes where p >= lo, Minimum where max(p,lo) <= hi

@@ -95,9 +95,9 @@ __device__ __forceinline__ void owner_role(const PersistArgs& a, int* go_flag, f
     const int ow = wg - G;                                  // owner workgroup index
     // four tiles per owner workgroup, on waves 0..3 = one wave per SIMD: a tile's 4 x rows/16 MFMAs have the matrix pipe of
     // their SIMD to themselves (with eight tiles per workgroup the multiplication took twice as long); waves 4..7 only
-    // keep the barriers company
+    // keep the barriers company (they issue no load and no MFMA: `live` guards the whole step body)
     const int t = ow * OWNER_TILES + wave;
-    const bool live = wave < OWNER_TILES && t < a.total_tiles;      // (idle waves shadow the last tile and store nothing)
+    const bool live = wave < OWNER_TILES && t < a.total_tiles;      // (idle waves read the last tile's record and touch nothing else)
     const DwTile T = a.tiles[live ? t : a.total_tiles - 1];
     unsigned* const flag_g = a.cnt + PCNT_FG;
     unsigned* const flag_w = a.cnt + PCNT_FW;
@@ -138,64 +138,66 @@ __device__ __forceinline__ void owner_role(const PersistArgs& a, int* go_flag, f
         __syncthreads();
         if (!*go_flag) return;
         OST(46);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-        for (int j0 = 0; j0 < n_active; j0 += 8) {          // 8 row blocks = 16 loads per lane in ONE round trip
-            f32x4 av[8], bv[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned jb = (unsigned)min(j0 + j, n_active - 1);
-                av[j] = load16_sc1(rA, jb * (unsigned)NFA * 64u + offA);
-                bv[j] = load16_sc1(rB, jb * (unsigned)NFB * 64u + offB);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // row blocks in pairs, in load order: the first MFMAs start when the first loads have landed (the waits count
-            // down vmcnt); block j feeds chain j & 3, as in the two-kernel step (same summation order per chain)
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const bool kin = (j0 + j + u) < n_active;
-#pragma unroll
+        float l2acc = 0.f;
+        if (live) {          // (wave-uniform) waves without a tile only keep the barriers company: no loads, no MFMAs
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+            for (int j0 = 0; j0 < n_active; j0 += 8) {          // 8 row blocks = 16 loads per lane in ONE round trip
+                f32x4 av[8], bv[8];
+    #pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned jb = (unsigned)min(j0 + j, n_active - 1);
+                    av[j] = load16_sc1(rA, jb * (unsigned)NFA * 64u + offA);
+                    bv[j] = load16_sc1(rB, jb * (unsigned)NFB * 64u + offB);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // row blocks in pairs, in load order: the first MFMAs start when the first loads have landed (the waits count
+                // down vmcnt); block j feeds chain j & 3, as in the two-kernel step (same summation order per chain)
+    #pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+    #pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const bool kin = (j0 + j + u) < n_active;
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            av[j + u][e] = ones ? 1.0f : av[j + u][e];
+                            bv[j + u][e] = kin ? bv[j + u][e] : 0.0f;
+                        }
+                    }
+    #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        av[j + u][e] = ones ? 1.0f : av[j + u][e];
-                        bv[j + u][e] = kin ? bv[j + u][e] : 0.0f;
+                        if ((j & 3) == 0) { MFMA16(av[j][e], bv[j][e], acc0); MFMA16(av[j + 1][e], bv[j + 1][e], acc1); }
+                        else              { MFMA16(av[j][e], bv[j][e], acc2); MFMA16(av[j + 1][e], bv[j + 1][e], acc3); }
                     }
                 }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if ((j & 3) == 0) { MFMA16(av[j][e], bv[j][e], acc0); MFMA16(av[j + 1][e], bv[j + 1][e], acc1); }
-                    else              { MFMA16(av[j][e], bv[j][e], acc2); MFMA16(av[j + 1][e], bv[j + 1][e], acc3); }
-                }
             }
-        }
-        OST(47);
-        float alpha = 0.f;
-        if (adam) alpha = a.lr * sqrtf(1.0f - b2pow) / (1.0f - b1pow);
-        float l2acc = 0.f;
-        float g[4], wn[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            g[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
-            const bool reg = ok[r] && l2on && (row0 + r) < fi;
-            g[r] = reg ? g[r] + a.l2 * w[r] : g[r];
-            l2acc += reg ? 0.5f * w[r] * w[r] : 0.f;
-            if (a.clip) g[r] = fminf(fmaxf(g[r], a.gmin), a.gmax);
-        }
-        opt_apply4(a.opt, a.lr, alpha, w, g, s0, s1, wn);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = ok[r] ? wn[r] : w[r];
-        if (adam) { b1pow *= 0.9f; b2pow *= 0.999f; }
-        // New weights into the image twin, 16 bytes per store: this lane's four fan-in rows of one column are one k-quad
-        // (rows past fan_in are the image's zero padding); the bias sits in a quad of its own whose other three words
-        // are unused.
-        if (live && col < fo) {
-            if (row0 < fi)
-                store16_sc1(r_img, (unsigned)(T.img_w + ((((row0 >> 2) * T.nn) + col) << 2)) * 4u,
-                            f32x4{w[0], row0 + 1 < fi ? w[1] : 0.f, row0 + 2 < fi ? w[2] : 0.f, row0 + 3 < fi ? w[3] : 0.f});
-            if (row0 <= fi && fi <= row0 + 3) {
-                const int rb = fi - row0;
-                const float bval = rb == 0 ? w[0] : (rb == 1 ? w[1] : (rb == 2 ? w[2] : w[3]));
-                store16_sc1(r_img, (unsigned)(T.img_b + 4 * col) * 4u, f32x4{bval, 0.f, 0.f, 0.f});
+            OST(47);
+            float alpha = 0.f;
+            if (adam) alpha = a.lr * sqrtf(1.0f - b2pow) / (1.0f - b1pow);
+            float g[4], wn[4];
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                g[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+                const bool reg = ok[r] && l2on && (row0 + r) < fi;
+                g[r] = reg ? g[r] + a.l2 * w[r] : g[r];
+                l2acc += reg ? 0.5f * w[r] * w[r] : 0.f;
+                if (a.clip) g[r] = tf_clip(g[r], a.gmin, a.gmax);
+            }
+            opt_apply4(a.opt, a.lr, alpha, w, g, s0, s1, wn);
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = ok[r] ? wn[r] : w[r];
+            if (adam) { b1pow *= 0.9f; b2pow *= 0.999f; }
+            // New weights into the image twin, 16 bytes per store: this lane's four fan-in rows of one column are one k-quad
+            // (rows past fan_in are the image's zero padding); the bias sits in a quad of its own whose other three words
+            // are unused.
+            if (live && col < fo) {
+                if (row0 < fi)
+                    store16_sc1(r_img, (unsigned)(T.img_w + ((((row0 >> 2) * T.nn) + col) << 2)) * 4u,
+                                f32x4{w[0], row0 + 1 < fi ? w[1] : 0.f, row0 + 2 < fi ? w[2] : 0.f, row0 + 3 < fi ? w[3] : 0.f});
+                if (row0 <= fi && fi <= row0 + 3) {
+                    const int rb = fi - row0;
+                    const float bval = rb == 0 ? w[0] : (rb == 1 ? w[1] : (rb == 2 ? w[2] : w[3]));
+                    store16_sc1(r_img, (unsigned)(T.img_b + 4 * col) * 4u, f32x4{bval, 0.f, 0.f, 0.f});
+                }
             }
         }
         if (last) {             // L2 term of the last mini-batch's cost (pre-update weights), one partial per owner workgroup
@@ -233,6 +235,9 @@ __global__ __launch_bounds__(FTHREADS) void persist_train_kernel(const PersistAr
     const int wave = UNI(tid >> 6);
     const int c = lane & 15, q = lane >> 4;
     const int wg = blockIdx.x, G = a.G;
+    // The error word is sticky across the launches of one smrt_vae_train_epochs call (api.hip: enqueue_persist_epoch): a
+    // launch that follows a timed-out one leaves at once -- weights, slots and step scalars stay as that epoch found them.
+    if (__hip_atomic_load(a.cnt + PCNT_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     if (wg >= G) { owner_role(a, &go_flag, red); return; }
 
     const int Z = a.Z;

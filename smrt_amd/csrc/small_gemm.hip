@@ -168,7 +168,7 @@ __device__ __forceinline__ void small_gemm_body(const GemmArgs& a, unsigned gx) 
         for (int c = 0; c < 4; ++c) if (cin[c]) {
             const float p = fast_sigmoid(v[c] + pb[c]);
             const float x = px[c];
-            const float pl = fmaxf(p, a.lo), pc = fminf(pl, a.hi), om = 1.0f - pc;
+            const float pl = tf_maximum(p, a.lo), pc = tf_minimum(pl, a.hi), om = 1.0f - pc;
             lsum -= x * __logf(pc) + (1.0f - x) * __logf(om);
             const bool pass = (p >= a.lo) && (pl <= a.hi);
             const float dp = pass ? -(x * __builtin_amdgcn_rcpf(pc) - (1.0f - x) * __builtin_amdgcn_rcpf(om)) * a.inv_batch : 0.0f;

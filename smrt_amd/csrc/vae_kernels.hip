@@ -99,8 +99,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const GemmArgs a)
         float lsum = 0.f;
         auto bce_elem = [&](float v, float x, float b, float& dpre) {
             const float p = fast_sigmoid(v + b);
-            const float pl = fmaxf(p, a.lo);
-            const float pc = fminf(pl, a.hi);
+            const float pl = tf_maximum(p, a.lo);
+            const float pc = tf_minimum(pl, a.hi);
             const float om = 1.0f - pc;
             lsum -= x * __logf(pc) + (1.0f - x) * __logf(om);
             // TF clip_by_value gradient gate: Maximum passes where p >= lo, Minimum where max(p,lo) <= hi
@@ -628,7 +628,7 @@ __device__ __forceinline__ void optimizer_body(const OptArgs& a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float gj = gv[j];
-            if (a.clip) gj = fminf(fmaxf(gj, a.gmin), a.gmax);      // tf.clip_by_value, base.py:144
+            if (a.clip) gj = tf_clip(gj, a.gmin, a.gmax);      // tf.clip_by_value, base.py:144
             wv[j] = opt_update(a, wv[j], gj, s0v[j], s1v[j], alpha);
         }
         *reinterpret_cast<float4*>(a.W + i0) = make_float4(wv[0], wv[1], wv[2], wv[3]);

@@ -175,3 +175,22 @@ def test_all_finite_sweep_and_validation_error_text():
     with pytest.raises(ValueError) as theirs:
         check_array(X)
     assert str(ours.value) == str(theirs.value)
+
+
+def test_reference_import_name_is_an_alias():
+    """`from smrt.balance import smrt_balance` (smrt/balance/tests/test_smrt.py:9) works unchanged: `smrt` is the same
+    module objects as `smrt_amd`, not a second implementation."""
+    import smrt
+    import smrt_amd.autoencode
+    import smrt_amd.balance
+    from smrt.autoencode import AutoEncoder, VariationalAutoEncoder
+    from smrt.autoencode.autoencoder import VariationalAutoEncoder as V2
+    from smrt.balance import over_sample_balance, smote_balance, smrt_balance, under_sample_balance
+    from smrt.balance.smrt import smrt_balance as sb2
+    from smrt.utils import DEFAULT_SEED, get_random_state
+    assert smrt_balance is smrt_amd.balance.smrt_balance is sb2
+    assert VariationalAutoEncoder is smrt_amd.autoencode.VariationalAutoEncoder is V2
+    assert AutoEncoder is smrt_amd.autoencode.AutoEncoder
+    assert smrt.balance is smrt_amd.balance and DEFAULT_SEED == 42
+    assert callable(over_sample_balance) and callable(smote_balance) and callable(under_sample_balance)
+    assert get_random_state(7).seed_value == 7

@@ -269,3 +269,98 @@ def test_c1_trained_state_parity():
     assert a["cost_rel_max"] < 5e-6 and b["cost_rel_max"] < 5e-6
     assert a["param_abs_max"] < 1e-5 * a["param_scale"]
     assert a["generate_abs_max"] < 1e-5 and a["generate_rel_max_above_1e-3"] < 1e-4
+
+
+def test_c3_class_at_the_api_default_learning_rate():
+    """Config C3 says API defaults; bench.py and test_c3_full_size_balance train at learning_rate 0.005 because at the
+    default 0.05 the costs of most of C3's classes leave the finite numbers.  That this is the REFERENCE ALGORITHM in fp32
+    and not the kernels is asserted here on one such class (class 5 of the C3 generator: 5 000 x 784, N1, batch 128,
+    rms_prop, 20 epochs, lr 0.05), fitted by the HIP path and by the oracle in fp32 and in fp64 from the same initial
+    weights with the same Philox epsilon:
+      * the first 10 steps agree with the fp32 oracle at 1e-4 -- beyond that the recursion is chaotic at this step size: the
+        oracle's OWN fp32 and fp64 runs are 8e-4 apart after the first epoch (40 steps) and 1.6 % after the second;
+      * the fp32 oracle's cost becomes non-finite (p == 1.0f: float32(1 - 1e-10) == 1.0f is no upper clip, _ae_utils.py:31,
+        SURVEY 8 a-7) while the fp64 oracle's never does -- it is the reference's compute dtype, not the data;
+      * the HIP path's cost becomes non-finite too, within a few epochs of the oracle's, and STAYS non-finite as the
+        oracle's does: tf.clip_by_value hands the NaN gradient (inf * 0 in the output layer) on to the weights
+        (device_utils.hpp: tf_clip; fmaxf / fminf would swallow it and train on with +-5 in its place)."""
+    import json
+    import os
+    from smrt_amd.autoencode import VariationalAutoEncoder
+    rs = np.random.RandomState(42)
+    Xs, ys = [_mnist_shaped(rs, 50000)], [np.zeros(50000, dtype=np.int64)]
+    for k in range(1, 9):
+        Xs.append(_mnist_shaped(rs, 5000))
+        ys.append(np.full(5000, k))
+    X, y = np.vstack(Xs), np.concatenate(ys)
+    p = rs.permutation(len(y))
+    X = X[p][y[p] == 5]                                        # the rows of class 5 in the order smrt_balance sees them
+    ae = VariationalAutoEncoder(n_hidden=450, n_latent_factors=10, random_state=42).fit(X)       # API defaults
+    c_h = np.asarray(ae.epoch_costs_, np.float64)
+    gen_finite = bool(np.isfinite(ae.generate(64)).all())
+    ae.clean_session()
+    runs = {}
+    for name, dt in (("f32", np.float32), ("f64", np.float64)):
+        o = OracleVAE(784, [450], 10, seed=42, learning_rate=0.05, dtype=dt)
+        with np.errstate(all="ignore"):
+            o.fit(X, n_epochs=20, batch_size=128)
+        runs[name] = np.asarray(o.epoch_costs_, np.float64)
+    c32, c64 = runs["f32"], runs["f64"]
+    first_bad = lambda c: int(np.argmax(~np.isfinite(c))) if (~np.isfinite(c)).any() else None
+    rec = {"hip": [repr(v) for v in c_h], "oracle_f32": [repr(v) for v in c32], "oracle_f64": [repr(v) for v in c64],
+           "first_non_finite": {"hip": first_bad(c_h), "oracle_f32": first_bad(c32), "oracle_f64": first_bad(c64)},
+           "hip_generate_finite_after_fit": gen_finite}
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    json.dump(rec, open(os.path.join(out_dir, "c3_default_lr.json"), "w"), indent=1)
+    print("C3 class 5 at lr 0.05:", rec["first_non_finite"], "epoch 0/1 costs", c_h[:2], c32[:2], c64[:2])
+    assert abs(c_h[0] - c32[0]) < 2e-3 * c32[0] and abs(c32[0] - c64[0]) < 2e-3 * c64[0]
+    # the well-posed prefix: 10 steps (one epoch over the first 1 280 rows), same weights, same epsilon
+    ae = VariationalAutoEncoder(n_hidden=450, n_latent_factors=10, random_state=42, n_epochs=1).fit(X[:1280])
+    o = OracleVAE(784, [450], 10, seed=42, learning_rate=0.05)
+    o.fit(X[:1280], n_epochs=1, batch_size=128)
+    np.testing.assert_allclose(ae.epoch_costs_[0], o.epoch_costs_[0], rtol=RTOL)
+    _close(ae.sess.get_params(), flatten_params(o.params), "weights after 10 steps at lr 0.05")
+    ae.clean_session()
+    b_h, b_32, b_64 = first_bad(c_h), first_bad(c32), first_bad(c64)
+    assert b_64 is None, "the fp64 oracle left the finite numbers too: not the fp32 clip bound"
+    assert b_32 is not None and b_h is not None, rec["first_non_finite"]
+    assert abs(b_h - b_32) <= 3, rec["first_non_finite"]
+    assert not np.isfinite(c_h[b_h:]).any() and not np.isfinite(c32[b_32:]).any()
+    assert not gen_finite                                       # NaN weights decode to NaN rows, as the reference's would
+
+
+def test_c5_as_the_smrt_balance_call():
+    """Config C5 as the call the config describes: smrt_balance on 1 000 000 x 256 (1:50, 19 608 minority rows),
+    balance_ratio 0.1, N5 = 256-[1024]*4-(64,64), batch 4096, adam, 20 epochs -> 78 431 synthetic rows.  Counts, the original
+    rows bit-identical and first, and the synthetic block against the oracle's decode of the reference's numpy draws
+    through the trained weights (as test_c3_full_size_balance does for C3)."""
+    from smrt_amd.balance import smrt_balance
+    rs = np.random.RandomState(42)
+    n, D, n_minor = 1000000, 256, 19608
+    y = np.zeros(n, dtype=np.int64)
+    y[rs.choice(n, n_minor, replace=False)] = 1
+    mu = rs.normal(size=(2, D)).astype(np.float32)
+    X = rs.standard_normal(size=(n, D)).astype(np.float32)
+    X += mu[y]
+    np.negative(X, out=X); np.exp(X, out=X); X += 1.0; np.reciprocal(X, out=X)          # sigmoid, in place
+    Xb, yb, enc = smrt_balance(X, y, n_hidden=[1024] * 4, n_latent_factors=64, balance_ratio=0.1, batch_size=4096,
+                               learning_function="adam", learning_rate=0.001, n_epochs=20, random_state=42, shuffle=False,
+                               return_estimators=True)
+    target = int(0.1 * (n - n_minor))
+    need = target - n_minor
+    assert need == 78431 and Xb.shape == (n + need, D) and Xb.dtype == np.float64
+    assert np.unique(yb, return_counts=True)[1].tolist() == [n - n_minor, target]
+    np.testing.assert_array_equal(Xb[:n], X)
+    np.testing.assert_array_equal(yb[:n], y)
+    assert (yb[n:] == 1).all() and enc[0] is None
+    costs = np.asarray(enc[1].epoch_costs_)
+    assert len(costs) == 20 and np.all(np.isfinite(costs)) and costs[-1] < costs[0]
+    z = np.random.RandomState(42).normal(size=(need, 64))
+    o = OracleVAE(D, [1024] * 4, 64, seed=42)
+    o.params = [(W, b) for W, b in unflatten_params(enc[1].sess.get_params(), D, [1024] * 4, 64)]
+    block = Xb[n:]
+    assert np.isfinite(block).all() and block.min() >= 0.0 and block.max() <= 1.0
+    for r0 in (0, 30000, need - 4096):                                       # three 4096-row blocks of the 78 431
+        _close(block[r0:r0 + 4096], o.decode(z[r0:r0 + 4096]), "C5 synthetic rows %d.." % r0)
+    enc[1].clean_session()

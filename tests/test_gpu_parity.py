@@ -482,3 +482,84 @@ def test_persistent_early_stopping_and_ineligible_nets(monkeypatch, kernel_path)
     hd.train_epochs(X, B, 2)
     assert hd.last_epoch_launches > 2
     hd.close()
+
+
+def test_persistent_timeout_is_sticky_and_falls_back(monkeypatch, kernel_path):
+    """A persistent launch that gives up (a peer never became resident) raises an error word.  It must survive the epochs
+    queued behind it (the per-launch memset used to clear it), the launches behind it must leave untouched what
+    the failed epoch found, and smrt_vae_train_epochs must then run that epoch and the rest on the two-launch step.
+    The test hook raises the word in front of epoch 1's launch, exactly what a time-out in that launch leaves behind."""
+    if kernel_path != "fused":
+        pytest.skip("the persistent kernel belongs to the LDS-resident (fused) path")
+    from smrt_amd._hip import HipLibraryError
+    rs = np.random.RandomState(21)
+    D, hidden, Z, n, B = 64, [128], 16, 600, 128
+    o, hp, h2 = _persist_pair(monkeypatch, D, hidden, Z, "sigmoid", "rms_prop", B, rs)
+    X = rs.uniform(0, 1, size=(n, D))
+    nb = (n + B - 1) // B
+    c2, _ = h2.train_epochs(X, B, 4)
+    # (1) reported, not lost: epochs 2 and 3 run behind the failed one and must not clear the word
+    monkeypatch.setenv("SMRT_HIP_PERSIST_FAULT_EPOCH", "1")
+    monkeypatch.setenv("SMRT_HIP_PERSIST_NO_FALLBACK", "1")
+    with pytest.raises(HipLibraryError, match=r"\(-6\)"):
+        hp.train_epochs(X, B, 4)
+    # the handle is where epoch 0 left it: one complete epoch, nothing of the failed ones
+    assert hp.step_count == nb
+    monkeypatch.delenv("SMRT_HIP_PERSIST_FAULT_EPOCH")
+    monkeypatch.delenv("SMRT_HIP_PERSIST_NO_FALLBACK")
+    c_rest, _ = hp.train_epochs(X, B, 3)
+    np.testing.assert_allclose(c_rest, c2[1:], rtol=5e-5)
+    _close(hp.get_params(), h2.get_params(), "resumed after a reported time-out", rtol=5e-5)
+    assert hp.step_count == h2.step_count == 4 * nb
+    hp.close(); h2.close()
+    # (2) recovered: same fault, fallback allowed -> the call succeeds, results as the two-launch path's
+    o, hp, h2 = _persist_pair(monkeypatch, D, hidden, Z, "sigmoid", "rms_prop", B, rs)
+    c2, _ = h2.train_epochs(X, B, 4)
+    monkeypatch.setenv("SMRT_HIP_PERSIST_FAULT_EPOCH", "2")
+    cp, ms = hp.train_epochs(X, B, 4)
+    monkeypatch.delenv("SMRT_HIP_PERSIST_FAULT_EPOCH")
+    assert len(cp) == 4 and hp.last_epoch_launches >= 2 * nb          # the last epochs ran as two launches per mini-batch
+    np.testing.assert_allclose(cp, c2, rtol=5e-5)
+    _close(hp.get_params(), h2.get_params(), "after the fallback", rtol=5e-5)
+    for slot in (0, 1):
+        _close(hp.get_opt_state(slot), h2.get_opt_state(slot), "slot %d after the fallback" % slot, rtol=5e-5)
+    assert hp.step_count == 4 * nb
+    # with early stopping the word is read after every epoch
+    monkeypatch.setenv("SMRT_HIP_PERSIST_FAULT_EPOCH", "0")
+    ce, _ = hp.train_epochs(X, B, 2, early_stopping=True, min_change=1e-9)
+    monkeypatch.delenv("SMRT_HIP_PERSIST_FAULT_EPOCH")
+    c2e, _ = h2.train_epochs(X, B, 2, early_stopping=True, min_change=1e-9)
+    np.testing.assert_allclose(ce, c2e, rtol=1e-4)
+    hp.close(); h2.close()
+
+
+def test_persistent_budget_is_per_device_and_plannable(monkeypatch, kernel_path):
+    """The budget of co-resident persistent workgroups: derived from the device, overridable, and a handle can be told
+    which path to take so that concurrent fits do not race for it (fit_group plans in class order)."""
+    if kernel_path != "fused":
+        pytest.skip("the persistent kernel belongs to the LDS-resident (fused) path")
+    from smrt_amd import _hip
+    monkeypatch.delenv("SMRT_HIP_PERSIST_BUDGET", raising=False)
+    monkeypatch.setenv("SMRT_HIP_PERSIST", "1")
+    assert _hip.persistent_budget(0) == 160                         # 5/8 of 256 CUs, one rank on the GPU
+    rs = np.random.RandomState(3)
+    D, hidden, Z, n, B = 64, [128], 16, 300, 128
+    X = rs.uniform(0, 1, size=(n, D))
+    nb = (n + B - 1) // B
+    h = _handle(D, hidden, Z, max_batch=B)
+    need = h.persistent_workgroups(B)
+    assert need == 8 + 28 and h.persistent_workgroups(513) == 0
+    h.train_epochs(X, B, 2)
+    assert h.last_epoch_launches == 2
+    monkeypatch.setenv("SMRT_HIP_PERSIST_BUDGET", str(need - 1))    # does not fit: the two-launch step
+    assert _hip.persistent_budget(0) == need - 1
+    h.train_epochs(X, B, 2)
+    assert h.last_epoch_launches >= 2 * nb
+    h.set_persistent(1)                                             # planned by the caller: granted whatever the budget says
+    h.train_epochs(X, B, 2)
+    assert h.last_epoch_launches == 2
+    monkeypatch.delenv("SMRT_HIP_PERSIST_BUDGET")
+    h.set_persistent(0)
+    h.train_epochs(X, B, 2)
+    assert h.last_epoch_launches >= 2 * nb
+    h.close()
