@@ -252,14 +252,16 @@ def dp_c4_throughput(dist, dev, rank, world, rows_per_gpu=262144, global_batch=6
     plan = plan_stripes(n_rows, global_batch, world)
     n_local = sum(int(b[rank + 1] - b[rank]) for _, _, b in plan)
     g = torch.Generator(device=dev).manual_seed(42 + rank)
-    X = (torch.rand((n_local, d), generator=g, device=dev) * (torch.rand((n_local, d), generator=g, device=dev) > 0.8)).float()
+    ldx = _hip.row_stride(d)                                    # rows on 128-byte boundaries, as to_device_padded lays them out
+    X = torch.zeros((n_local, ldx), dtype=torch.float32, device=dev)
+    X[:, :d] = (torch.rand((n_local, d), generator=g, device=dev) * (torch.rand((n_local, d), generator=g, device=dev) > 0.8)).float()
     sess = _hip.VaeHandle(n_features=d, hidden=hidden, n_latent=z, activation="sigmoid", optimizer="adam",
                           learning_rate=0.001, l2_penalty=1e-4, clip=True, gclip_min=-5.0, gclip_max=5.0, eps=1e-10,
                           dropout=1.0, seed=42, max_batch=(global_batch + world - 1) // world + 1, device=dev.index)
     try:
         topo = VAETopography(n_hidden=hidden, input_shape=d, activation="sigmoid", n_latent_factors=z, random_state=42)
         sess.set_params(VAETopography.join_flat(topo.initial_parameters()))
-        tr = DataParallelTrainer(sess, (X, d), n_rows, global_batch, rank, world, dist)
+        tr = DataParallelTrainer(sess, (X, ldx), n_rows, global_batch, rank, world, dist)
         tr.run_epochs(1)                                        # warm-up (RCCL channels, kernels)
         torch.cuda.synchronize(dev)
         if dist is not None:

@@ -144,12 +144,20 @@ def sync_torch_stream(device):
     _torch().cuda.current_stream(device).synchronize()
 
 
+def row_stride(d):
+    """Leading dimension (floats) the wrapper gives device matrices of ``d`` columns: rows start on 128-byte boundaries
+    once they are longer than that (a wave's 128-byte row pieces then touch one cache line each, not two), 16-byte
+    boundaries otherwise.  The C ABI itself only asks for a multiple of 4."""
+    d = int(d)
+    return (d + 31) // 32 * 32 if d > 32 else rup4(d)
+
+
 def to_device_padded(array, device):
-    """Host [n, d] array -> contiguous fp32 device tensor [n, rup4(d)]; returns (tensor, ld)."""
+    """Host [n, d] array -> contiguous fp32 device tensor [n, row_stride(d)]; returns (tensor, ld)."""
     torch = _torch()
     a = np.ascontiguousarray(array, dtype=np.float32)
     n, d = a.shape
-    ld = rup4(d)
+    ld = row_stride(d)
     t = torch.zeros((n, ld), dtype=torch.float32, device=device)
     if n:
         t[:, :d] = torch.from_numpy(a).to(device)

@@ -77,7 +77,7 @@ struct smrt_vae {
     float* dpreT[MAX_LAYERS] = {nullptr};
     float *XT = nullptr, *ZT = nullptr;
     float *bce_p = nullptr, *kl_p = nullptr, *l2_p = nullptr;
-    int n_l2 = 0;
+    int n_l2 = 0, l2_cap = 0;            // l2 partials of the optimizer sweep; capacity of l2_p
     float* cost_dev = nullptr; long cost_cap = 0;
     float* cost_pin = nullptr; long cost_pin_cap = 0;
     unsigned* err_pin = nullptr;         // per-epoch copies of the persistent kernel's error word (same capacity as cost_pin)
@@ -148,7 +148,7 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------ layout helpers
-static void build_layers(smrt_vae* h) {
+static void build_layers(smrt_vae* h, int ld_align) {
     const smrt_vae_cfg& c = h->cfg;
     h->ae = (c.model == SMRT_MODEL_AE);
     h->L = c.n_hidden_layers; h->D = c.n_features;
@@ -159,7 +159,7 @@ static void build_layers(smrt_vae* h) {
     int li = 0; long off = 0, pabi = 0; int maxld = rup4(c.n_features);
     auto add = [&](int fi, int fo, int act, int l2) {
         LayerI& y = h->lay[li++];
-        y.fi = fi; y.fo = fo; y.ld = rup4(fo); y.off = off; y.act = act; y.l2 = l2;
+        y.fi = fi; y.fo = fo; y.ld = (fo + ld_align - 1) / ld_align * ld_align; y.off = off; y.act = act; y.l2 = l2;
         off += (long)(fi + 1) * y.ld;
         maxld = std::max(maxld, y.ld);
     };
@@ -417,9 +417,9 @@ static int ensure_train(smrt_vae* h, int rows) {
     HIPC(hipStreamSynchronize(h->stream));
     const int nsplit = std::max(splits, h->g_splits_cap);
     const int cap = (std::max(std::max(rows, h->cap_rows), (int)h->cfg.max_batch) + 15) & ~15;   // fused kernels store whole 16-row tiles
-    // loss partials: one per workgroup of the output-layer GEMM (64x64 tiles, or 32x32 in the small-batch kernels)
+    // loss partials: one per workgroup of the output-layer GEMM (64x64 tiles, or down to 16x16 in the small-batch kernels)
     const int nb = std::max(std::max(((cap + 63) / 64) * ((h->D + 63) / 64), (cap + 15) / 16),
-                            ((std::min(cap, SMALL_M_MAX) + 31) / 32) * ((h->D + 31) / 32));
+                            ((std::min(cap, SMALL_M_MAX) + 15) / 16) * ((h->D + 15) / 16));
     auto layout = [&](Arena& a) {
         a.off = 0;
         carve(a, &h->G, (size_t)nsplit * h->P_int);
@@ -675,7 +675,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         ma.DOUT = h->dpre[HL - 1]; ma.lddo = h->lay[HL - 1].ld;
         ma.M = rows; ma.hL = yh.fi; ma.Z = Z; ma.act = yh.act; ma.inv_batch = inv_batch;
         ma.seed = h->cfg.seed; ma.st = h->st; ma.row0_global = row0_global;
-        n_kl = mid_row_blocks(rows);
+        n_kl = mid_row_blocks(rows, yh.fi);
     }
     // ---- forward
     for (int l = 0; l < NL && !fused_step; ++l) {
@@ -798,11 +798,34 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             q.C = h->G + y.off; q.ldc = y.ld; q.fi = y.fi; q.fo = y.fo;
             q.tiles_n = (y.fo + t - 1) / t; q.tile_begin = tb;
             tb += ((y.fi + (small ? 1 : 0) + t - 1) / t) * q.tiles_n;
+            q.off = y.off; q.l2 = y.l2;
         }
         d.n_layers = NL; d.total_tiles = tb; d.rows = rows; d.splits = splits;
         d.k_per_split = (((rows + splits - 1) / splits) + 31) & ~31;
         d.slab_stride = h->P_int;
         if (!small) d.total_tiles = plan_dw_units(h, big, splits, &d, nullptr);      // (tile, K range) work units
+        // Small mini-batches, a full step, no dropout: the weight-gradient launch applies the update itself (small_gemm.hip:
+        // small_dw_opt) -- one launch fewer per mini-batch, no gradient slab, no optimizer sweep.
+        static const bool dwopt_env = []() { const char* e = std::getenv("SMRT_HIP_DW_OPT"); return e ? std::atoi(e) != 0 : true; }();
+        if (small && mode == 0 && !h->has_drop && dwopt_env && tb <= h->l2_cap) {
+            d.W = h->W; d.s0 = h->s0; d.s1 = h->s1; d.grad_out = o.grad_out; d.l2_partials = h->l2_p; d.st = h->st;
+            d.opt = h->cfg.optimizer; d.clip = h->cfg.clip; d.has_l2 = h->has_l2 ? 1 : 0;
+            d.lr = h->cfg.learning_rate; d.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
+            d.gmin = h->cfg.gclip_min; d.gmax = h->cfg.gclip_max;
+            d.advance = h->cfg.optimizer != 2;          // (as the sweep: under Adam every block reads the powers, finalize advances)
+            { ProfScope ps(h, PK_DW); launch_small_dw_opt(s, d); } ++launches;
+            h->img_valid = false;
+            if (o.cost_slot || !d.advance) {
+                FinalizeArgs f{};
+                f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p; f.n_l2 = tb;
+                f.inv_batch = h->ae ? inv_batch / (float)h->D : inv_batch; f.l2 = d.l2;
+                f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
+                f.st = h->st; f.advance = d.advance ? 0 : 1;
+                { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
+            }
+            h->last_epoch_launches = launches;
+            return 0;
+        }
         { ProfScope ps(h, PK_DW); if (small) launch_small_dw(s, d); else launch_dw(s, d, big); } ++launches;
     }
     if (mode == 1) {
@@ -863,8 +886,15 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
     HIPC(hipSetDevice(device));
     smrt_vae* h = new smrt_vae();
     h->cfg = *cfg; h->device = device;
-    build_layers(h);
+    // Leading dimensions (weights, and with them every activation / gradient buffer): a multiple of 4 floats for nets on the
+    // LDS-resident path (their global buffers are blocked transposed, the flat one only feeds the image twin), a multiple of
+    // 32 floats = 128 bytes otherwise.  With rows of 452 floats (the reference's 450-wide layer) every 128-byte row piece a
+    // wave loads or stores straddles two cache lines; measured on the reference's own net at batch 128 against the same
+    // net with 448 / 768-wide layers: weight-gradient launch 10.0 -> 7.5 us, every other launch 0.5-1 us.
+    static const int ld_env = []() { const char* e = std::getenv("SMRT_HIP_LD_ALIGN"); return e ? std::atoi(e) : 32; }();
+    build_layers(h, 4);
     plan_fused(h);
+    if (!h->fused && ld_env > 4 && ld_env % 4 == 0) { build_layers(h, ld_env); plan_fused(h); }
     h->has_drop = cfg->dropout_keep < 1.0f;
     h->has_l2 = cfg->l2_penalty >= 0.f;
     const char* g = std::getenv("SMRT_HIP_GRAPH");
@@ -875,6 +905,9 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
     int rc;
     h->n_l2 = optimizer_blocks(h->P_int);
     {
+        int dw32 = 0;
+        for (int l = 0; l < h->NL; ++l) dw32 += ((h->lay[l].fi + 1 + 31) / 32) * ((h->lay[l].fo + 31) / 32);
+        h->l2_cap = std::max(std::max(h->n_l2, dw_opt_blocks(h->tiles16)), dw32);
         auto layout = [&](Arena& a) {
             a.off = 0;
             carve(a, &h->W, (size_t)h->P_int);
@@ -885,7 +918,7 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
             carve(a, &h->ticket, (size_t)4);
             carve(a, &h->pcnt, (size_t)256);
             carve(a, &h->cost_dev, (size_t)4);
-            carve(a, &h->l2_p, (size_t)std::max(h->n_l2, dw_opt_blocks(h->tiles16)));      // (>= persist_owner_workgroups)
+            carve(a, &h->l2_p, (size_t)h->l2_cap);     // (>= persist_owner_workgroups, >= the 32x32 tiles of small_dw_opt)
             carve(a, &h->stage_tab, h->fused ? (size_t)h->P_int / 4 : 0);
             carve(a, &h->gtmp, (size_t)h->P_int + 4);
             carve(a, &h->Wd, h->has_drop ? (size_t)h->P_int : 0);
@@ -1282,8 +1315,9 @@ int smrt_vae_train_epochs_multi(smrt_vae** hs, int32_t n_handles, const float* c
             const int rows = (int)std::min<long>(batch_size, n_rows[k] - r0);
             StepOut o{(b == nb - 1) ? h->cost_dev : nullptr, nullptr, nullptr};
             g_record.out = &rec[k][b];
+            g_record.group = n_handles;                  // (tile shapes are picked for the grouped grid)
             const int rc = enqueue_step(h, X_dev[k] + r0 * ldx[k], ldx[k], rows, 1.0f / (float)rows, 0, nullptr, 0, o);
-            g_record.out = nullptr;
+            g_record.out = nullptr; g_record.group = 1;
             if (rc) return rc;
         }
         max_steps = std::max(max_steps, (size_t)nb);

@@ -91,6 +91,38 @@ __device__ __forceinline__ void act_bwd4(int act, const float (&y)[4], float (&d
     }
 }
 
+// ---------------------------------------------------------------- optimizer arithmetic (per-layer path)
+// One element of tf.train.*Optimizer.apply_gradients as the reference constructs them (autoencoder.py:38-48, base.py:138-149;
+// [TF-sem] slot initial values and epsilon placement are in api.hip: smrt_vae_reset_opt_state and SURVEY 8 a-9), with IEEE
+// sqrt and divide.  Shared by the optimizer sweep (vae_kernels.hip) and the fused weight-gradient + update launch
+// (small_gemm.hip), so both give the same bits for the same gradient.
+__device__ __forceinline__ float opt_update_ieee(int opt, float lr, float alpha, float w, float g, float& s0, float& s1) {
+    switch (opt) {
+        case 1: {   // RMSProp: decay .9, momentum 0, eps 1e-10, rms slot starts at 1
+            s0 = s0 + (g * g - s0) * (1.0f - 0.9f);
+            s1 = s1 * 0.0f + lr * g / sqrtf(s0 + 1e-10f);
+            return w - s1;
+        }
+        case 2: {   // Adam: alpha = lr * sqrt(1 - b2^t) / (1 - b1^t), eps 1e-8 outside the sqrt
+            s0 = s0 + (g - s0) * (1.0f - 0.9f);
+            s1 = s1 + (g * g - s1) * (1.0f - 0.999f);
+            return w - alpha * s0 / (sqrtf(s1) + 1e-8f);
+        }
+        case 3: case 6: {   // Adagrad / ProximalAdagrad(l1 = l2 = 0): accumulator starts at 0.1
+            s0 = s0 + g * g;
+            return w - lr * g / sqrtf(s0);
+        }
+        case 4: {   // Adadelta: rho .95, eps 1e-8
+            s0 = s0 * 0.95f + g * g * (1.0f - 0.95f);
+            const float upd = sqrtf(s1 + 1e-8f) / sqrtf(s0 + 1e-8f) * g;
+            s1 = s1 * 0.95f + upd * upd * (1.0f - 0.95f);
+            return w - lr * upd;
+        }
+        default:    // SGD / ProximalGradientDescent(l1 = l2 = 0)
+            return w - lr * g;
+    }
+}
+
 // ---------------------------------------------------------------- Philox4x32-10
 // Counter-based RNG (Salmon et al., SC'11).  Streams: 1 = training epsilon, 2 = dropout, 3 = generate.
 // Mirrored bit-for-bit by oracle/vae_oracle.py: philox4x32_10.

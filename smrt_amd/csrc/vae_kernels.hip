@@ -541,30 +541,7 @@ void launch_dropout(hipStream_t s, const DropArgs& a) {
 // Fused slab-reduce + L2 + dropout-backward + value clip + optimizer update     base.py:127-149
 // =====================================================================================
 __device__ __forceinline__ float opt_update(const OptArgs& a, float w, float g, float& s0, float& s1, float alpha) {
-    switch (a.opt) {
-        case 1: {   // RMSProp: decay .9, momentum 0, eps 1e-10, rms slot starts at 1
-            s0 = s0 + (g * g - s0) * (1.0f - 0.9f);
-            s1 = s1 * 0.0f + a.lr * g / sqrtf(s0 + 1e-10f);
-            return w - s1;
-        }
-        case 2: {   // Adam: alpha = lr * sqrt(1 - b2^t) / (1 - b1^t), eps 1e-8 outside the sqrt
-            s0 = s0 + (g - s0) * (1.0f - 0.9f);
-            s1 = s1 + (g * g - s1) * (1.0f - 0.999f);
-            return w - alpha * s0 / (sqrtf(s1) + 1e-8f);
-        }
-        case 3: case 6: {   // Adagrad / ProximalAdagrad(l1 = l2 = 0): accumulator starts at 0.1
-            s0 = s0 + g * g;
-            return w - a.lr * g / sqrtf(s0);
-        }
-        case 4: {   // Adadelta: rho .95, eps 1e-8
-            s0 = s0 * 0.95f + g * g * (1.0f - 0.95f);
-            const float upd = sqrtf(s1 + 1e-8f) / sqrtf(s0 + 1e-8f) * g;
-            s1 = s1 * 0.95f + upd * upd * (1.0f - 0.95f);
-            return w - a.lr * upd;
-        }
-        default:    // SGD / ProximalGradientDescent(l1 = l2 = 0)
-            return w - a.lr * g;
-    }
+    return opt_update_ieee(a.opt, a.lr, alpha, w, g, s0, s1);
 }
 
 __device__ __forceinline__ void optimizer_body(const OptArgs& a) {

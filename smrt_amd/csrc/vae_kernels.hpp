@@ -65,7 +65,7 @@ struct RecordedLaunch {
     std::vector<char> args;                 // bytes of its single argument struct (empty: has no grouped twin)
     std::function<void(hipStream_t)> plain; // issues the launch as it was recorded
 };
-struct Recorder { std::vector<RecordedLaunch>* out = nullptr; };
+struct Recorder { std::vector<RecordedLaunch>* out = nullptr; int group = 1; };   // group: handles recorded side by side
 extern thread_local Recorder g_record;
 
 struct MultiInfo { const void* multi; size_t arg_size, slot_size, gx_off; };
@@ -146,6 +146,7 @@ struct GemmArgs {
     int act, Z;
     float lo, hi, inv_batch;
     unsigned long long* dbg;            // diagnostic builds only (-DSMRT_STAMPS)
+    int xmap, pad_;                     // small-batch kernels: workgroup -> tile map (0 as dispatched, 1 / 2 XCD chunks, small_gemm.hip)
 };
 
 struct DwLayer {
@@ -159,6 +160,9 @@ struct DwLayer {
     // last row of tiles / corner -- decides into how many K ranges it is cut (see plan_dw_units in api.hip)
     int tiles_m;
     int s_cls[4];
+    // fused weight-gradient + update launch (small_gemm.hip: small_dw_opt) only
+    long off;            // start of the layer's augmented matrix in the flat parameter / slot buffers
+    int l2, pad_;        // the layer is regularised (the heads are not, layer.py:96)
 };
 struct DwArgs {
     DwLayer L[MAX_LAYERS];
@@ -166,6 +170,13 @@ struct DwArgs {
     int rows, k_per_split, splits;
     long slab_stride;
     int ycum[33];        // tiled kernel: work units in front of K-range index y (units are ordered range-major)
+    // fused weight-gradient + update launch only: a tile's owner applies L2, clip and the optimizer to its 32x32 elements
+    float* W; float* s0; float* s1;
+    float* grad_out;     // optional: pre-clip gradient wrt the variables (internal layout)
+    float* l2_partials;  // one per tile
+    DevState* st;
+    int opt, clip, has_l2, advance;
+    float lr, l2, gmin, gmax;
 };
 
 struct OptSeg {
@@ -228,10 +239,12 @@ struct MidArgs {
     int M, hL, Z, act;
     float inv_batch;
     uint64_t seed; const DevState* st; long row0_global;
+    int xmap, pad_;                                  // workgroup -> tile map (small_gemm.hip: xcd_tile)
 };
 void launch_mid_fwd(hipStream_t s, const MidArgs& a);
 void launch_mid_bwd(hipStream_t s, const MidArgs& a);
-int  mid_row_blocks(int rows);
+int  mid_row_blocks(int rows, int hL);
+int  small_tile_shape(int M, int N);                  // 22 | 12 | 11: (16 MT) x (16 NT) tile of a small-batch launch
 
 struct FinalizeArgs {
     const float* bce; int n_bce;
@@ -363,11 +376,12 @@ int  dw_opt_blocks(int total_tiles);
 int  fused_set_max_lds(int bytes);
 void launch_build_image(hipStream_t s, const float* Wflat, const int* tab, float* img, int n_f4);
 
-constexpr int SMALL_M_MAX = 512;    // mini-batches up to this many rows take the register-fed 32x32-tile kernels (small_gemm.hip)
+constexpr int SMALL_M_MAX = 512;    // mini-batches up to this many rows take the register-fed small-tile kernels (small_gemm.hip)
 void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a);
 void launch_small_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a);
 int  small_gemm_blocks(const GemmArgs& a);
 void launch_small_dw(hipStream_t s, const DwArgs& a);
+void launch_small_dw_opt(hipStream_t s, const DwArgs& a);
 int  gemm_grid_blocks(int kind, const GemmArgs& a);          // number of blocks (= BCE partial count)
 void launch_dw(hipStream_t s, const DwArgs& a, bool big);
 void launch_optimizer(hipStream_t s, const OptArgs& a, int* n_blocks_out);

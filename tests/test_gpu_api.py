@@ -270,3 +270,44 @@ def test_grouped_class_fits_are_bit_identical_to_separate_fits(monkeypatch):
     o = OracleVAE(D, [300], 7, learning_function="adam", learning_rate=0.002, seed=3)
     o.fit(X[y == 2], n_epochs=3, batch_size=64)
     np.testing.assert_allclose(eg[2].epoch_costs_, np.array(o.epoch_costs_), rtol=1e-4)
+
+
+@pytest.mark.parametrize("D,hidden,Z,B,act,opt", [(784, [450], 10, 128, "sigmoid", "rms_prop"),     # the reference's own net and batch
+                                                  (203, [77, 45], 6, 83, "tanh", "adagrad"),       # ragged everything, two hidden layers
+                                                  (90, [300], 16, 256, "relu", "sgd")])
+def test_small_batch_tile_shapes_agree_bit_for_bit(monkeypatch, D, hidden, Z, B, act, opt):
+    """small_gemm.hip picks the tile of a small-batch launch -- 32x32, 16x32 or 16x16 outputs per workgroup -- by how many
+    workgroups the grid then has; every shape sums a wave's k-blocks in the same order, so WHICH shape ran must not show
+    in any number: three steps (injected epsilon, ragged last batch) with each shape forced, then cost, every gradient,
+    the weights and encode / decode compared bit for bit; and against the oracle at 1e-4."""
+    from smrt_amd import _hip
+    from oracle.vae_oracle import flatten_params
+    monkeypatch.setenv("SMRT_HIP_FUSED", "0")
+    rs = np.random.RandomState(D)
+    o = OracleVAE(D, hidden, Z, activation=act, learning_function=opt, learning_rate=0.01, seed=4)
+    o.params = [((W + 0.05 * rs.normal(size=W.shape)).astype(np.float32), (b + 0.05 * rs.normal(size=b.shape)).astype(np.float32))
+                for W, b in o.params]
+    p0 = flatten_params(o.params).copy()
+    steps = [(rs.uniform(0, 1, size=(n, D)), rs.normal(size=(n, Z))) for n in (B, B, max(B // 3, 1))]
+    got = {}
+    for shape in ("22", "12", "11"):
+        monkeypatch.setenv("SMRT_HIP_SMALL_TILE", shape)
+        h = _hip.VaeHandle(n_features=D, hidden=hidden, n_latent=Z, activation=act, optimizer=opt, learning_rate=0.01,
+                           l2_penalty=1e-4, clip=True, gclip_min=-5.0, gclip_max=5.0, eps=1e-10, dropout=1.0, seed=4,
+                           max_batch=B, device=0)
+        h.set_params(p0)
+        outs = []
+        for X, eps in steps:
+            c, g = h.train_step(X, eps, want_grads=True)
+            outs += [np.float32(c), g]
+        mu, ls = h.encode(steps[0][0][:50])
+        outs += [h.get_params(), mu, ls, h.decode(steps[0][1][:50])]
+        got[shape] = outs
+        h.close()
+    for shape in ("12", "11"):
+        for k, (a, b) in enumerate(zip(got["22"], got[shape])):
+            np.testing.assert_array_equal(a, b, err_msg="tile shape %s differs from 32x32 in output %d" % (shape, k))
+    for k, (X, eps) in enumerate(steps):
+        c_o = o.train_step(X, eps)
+        assert np.isclose(got["11"][2 * k], c_o, rtol=1e-4), (k, got["11"][2 * k], c_o)
+    np.testing.assert_allclose(got["11"][6], flatten_params(o.params), rtol=1e-4, atol=1e-5)

@@ -40,8 +40,9 @@ def flops(net):
 
 def synth(n, D, seed=0):
     import torch
+    from smrt_amd import _hip
     g = torch.Generator(device="cuda").manual_seed(seed)
-    ld = (D + 3) // 4 * 4
+    ld = _hip.row_stride(D)
     X = torch.zeros((n, ld), dtype=torch.float32, device="cuda")
     X[:, :D] = torch.rand((n, D), generator=g, device="cuda")
     torch.cuda.synchronize()
