@@ -106,6 +106,8 @@ struct smrt_vae {
     float* Wimg = nullptr;           // LDS-image twin of the parameters (fplan.img_total floats)
     bool img_valid = false;          // Wimg matches W (kept current by the fused optimizer epilogue)
     DwTile* tile_tab = nullptr;      // per-tile records of the fused dW + optimizer kernel
+    DwRec* dwrec = nullptr;          // small-batch fused weight-gradient + update launch: 32x32 tile records, then 64x64 ones
+    int n_rec32 = 0, n_rec64 = 0;
     // persistent whole-epoch kernel (persist_train.hip)
     bool persist_ok = false;         // the net qualifies (fits in LDS, no dropout, VAE)
     unsigned* pcnt = nullptr;        // producer flags + error word (256 words)
@@ -431,6 +433,7 @@ static int ensure_train(smrt_vae* h, int rows) {
         carve(a, &h->Eb, (size_t)cap * rup4(h->Z));
         carve(a, &h->bce_p, (size_t)nb);
         carve(a, &h->kl_p, (size_t)std::max(reparam_blocks(cap, h->Z), (cap + 15) / 16));
+        carve(a, &h->dwrec, (size_t)(h->n_rec32 + h->n_rec64));
         if (h->fused) {
             for (int l = 0; l < h->NL; ++l) {
                 carve(a, &h->outT[l], (l < h->NL - 1) ? (size_t)cap * rup16(h->lay[l].fo) : 0);
@@ -441,12 +444,36 @@ static int ensure_train(smrt_vae* h, int rows) {
             carve(a, &h->tile_tab, (size_t)h->tiles16);
         }
     };
+    h->n_rec32 = h->n_rec64 = 0;
+    for (int l = 0; l < h->NL; ++l) {
+        h->n_rec32 += ((h->lay[l].fi + 1 + 31) / 32) * ((h->lay[l].fo + 31) / 32);
+        h->n_rec64 += ((h->lay[l].fi + 1 + 63) / 64) * ((h->lay[l].fo + 63) / 64);
+    }
     Arena dry;
     layout(dry);
     TRY(arena_alloc(h->ta, dry.off, h->stream));
     layout(h->ta);
     h->g_splits_cap = nsplit;
     h->cap_rows = cap;
+    {   // tile records of the small-batch fused weight-gradient + update launch (the workspace pointers are fixed from here on)
+        std::vector<DwRec> recs;
+        for (int t : {32, 64})
+            for (int l = 0; l < h->NL; ++l) {
+                const LayerI& y = h->lay[l];
+                const bool from_x = (l == 0), from_z = (l == h->hl + 1 && !h->ae);
+                for (int m0 = 0; m0 <= y.fi; m0 += t)
+                    for (int n0 = 0; n0 < y.fo; n0 += t) {
+                        DwRec r{};
+                        r.A = from_x ? nullptr : (from_z ? h->Zb : h->out[l - 1]);
+                        r.lda = from_x ? 0 : (from_z ? rup4(h->Z) : h->lay[l - 1].ld);
+                        r.B = h->dpre[l]; r.ldb = y.ld; r.ldc = y.ld; r.off = y.off; r.fi = y.fi; r.fo = y.fo;
+                        r.m0 = m0; r.n0 = n0; r.l2 = y.l2;
+                        recs.push_back(r);
+                    }
+            }
+        if ((int)recs.size() != h->n_rec32 + h->n_rec64) return fail(-4, "internal: weight-gradient record count mismatch");
+        HIPC(hipMemcpy(h->dwrec, recs.data(), recs.size() * sizeof(DwRec), hipMemcpyHostToDevice));
+    }
     if (h->fused) {
         std::vector<DwTile> tiles;
         for (int l = 0; l < h->NL; ++l) {
@@ -679,7 +706,28 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
     }
     // ---- forward
     for (int l = 0; l < NL && !fused_step; ++l) {
-        if (mid && l == HL) { ProfScope ps(h, PK_FWD); launch_mid_fwd(s, ma); ++launches; continue; }
+        if (mid && l == HL) {
+#ifdef SMRT_STAMPS
+            static unsigned long long* mdbg = nullptr;
+            if (!mdbg) { (void)hipMalloc((void**)&mdbg, 64 * 8); (void)hipMemset(mdbg, 0, 64 * 8); }
+            ma.dbg = mdbg;
+#endif
+            { ProfScope ps(h, PK_FWD); launch_mid_fwd(s, ma); } ++launches;
+#ifdef SMRT_STAMPS
+            {
+                (void)hipStreamSynchronize(s);
+                unsigned long long hb[64];
+                (void)hipMemcpy(hb, mdbg, 64 * 8, hipMemcpyDeviceToHost);
+                static int once = 0;
+                if (once++ == 4) for (int b = 0; b < 3; ++b)
+                    fprintf(stderr, "mid_fwd wg %s: start +%.2f us after wg 0 | heads tile %.2f | reparam %.2f | dec1 tile %.2f\n",
+                            b == 0 ? "first" : (b == 1 ? "middle" : "last"), ((double)hb[16 * b] - (double)hb[0]) * 0.01,
+                            (double)(hb[16 * b + 1] - hb[16 * b]) * 0.01, (double)(hb[16 * b + 2] - hb[16 * b + 1]) * 0.01,
+                            (double)(hb[16 * b + 3] - hb[16 * b + 2]) * 0.01);
+            }
+#endif
+            continue;
+        }
         if (mid && l == HL + 1) continue;
         const LayerI& y = h->lay[l];
         GemmArgs a{};
@@ -788,6 +836,54 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         d.G = h->G; d.slab_stride = h->P_int;
         { ProfScope ps(h, PK_DW); launch_fused_dw_slab(s, d, splits); } ++launches;
     } else {
+        // Small mini-batches, a full step, no dropout: the weight-gradient launch applies the update itself (small_gemm.hip:
+        // small_dw_opt) -- one launch fewer per mini-batch, no gradient slab, no optimizer sweep.  32x32 tiles, or 64x64 on
+        // request (SMRT_HIP_DW64=1: half the operand traffic, measured no faster).
+        static const int dw64_env = []() { const char* e = std::getenv("SMRT_HIP_DW64"); return e ? std::atoi(e) : 0; }();
+        static const bool dwopt_env = []() { const char* e = std::getenv("SMRT_HIP_DW_OPT"); return e ? std::atoi(e) != 0 : true; }();
+        if (small && mode == 0 && !h->has_drop && dwopt_env && h->n_rec32 <= h->l2_cap) {
+            const bool dw64 = dw64_env != 0 && small_dw64_available();
+            DwFusedArgs d{};
+            d.tiles = dw64 ? h->dwrec + h->n_rec32 : h->dwrec; d.total_tiles = dw64 ? h->n_rec64 : h->n_rec32; d.rows = rows;
+            d.X = X; d.ldx = ldx;
+            d.W = h->W; d.s0 = h->s0; d.s1 = h->s1; d.grad_out = o.grad_out; d.l2_partials = h->l2_p; d.st = h->st;
+            d.opt = h->cfg.optimizer; d.clip = h->cfg.clip; d.has_l2 = h->has_l2 ? 1 : 0;
+            d.lr = h->cfg.learning_rate; d.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
+            d.gmin = h->cfg.gclip_min; d.gmax = h->cfg.gclip_max;
+            d.advance = h->cfg.optimizer != 2;          // (as the sweep: under Adam every block reads the powers, finalize advances)
+            d.want_l2 = (o.cost_slot || !d.advance) ? 1 : 0;
+#ifdef SMRT_STAMPS
+            static unsigned long long* ddbg = nullptr;
+            if (!ddbg) { (void)hipMalloc((void**)&ddbg, 64 * 8); (void)hipMemset(ddbg, 0, 64 * 8); }
+            d.dbg = ddbg;
+#endif
+            { ProfScope ps(h, PK_DW); if (dw64) launch_small_dw64_opt(s, d); else launch_small_dw_opt(s, d); } ++launches;
+#ifdef SMRT_STAMPS
+            {
+                (void)hipStreamSynchronize(s);
+                unsigned long long hb[64];
+                (void)hipMemcpy(hb, ddbg, 64 * 8, hipMemcpyDeviceToHost);
+                static int once = 0;
+                if (once++ == 4) for (int b = 0; b < 3; ++b)
+                    fprintf(stderr, "dw_opt wg %s: start +%.2f us after wg 0 | set-up + slot requests %.2f | tile %.2f | update + stores issued %.2f | stores drained %.2f | l2 partial %.2f\n",
+                            b == 0 ? "first" : (b == 1 ? "middle" : "last"), ((double)hb[16 * b] - (double)hb[0]) * 0.01,
+                            (double)(hb[16 * b + 1] - hb[16 * b]) * 0.01, (double)(hb[16 * b + 2] - hb[16 * b + 1]) * 0.01,
+                            (double)(hb[16 * b + 3] - hb[16 * b + 2]) * 0.01, (double)(hb[16 * b + 4] - hb[16 * b + 3]) * 0.01,
+                            (double)(hb[16 * b + 5] - hb[16 * b + 4]) * 0.01);
+            }
+#endif
+            h->img_valid = false;
+            if (o.cost_slot || !d.advance) {
+                FinalizeArgs f{};
+                f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p; f.n_l2 = d.total_tiles;
+                f.inv_batch = h->ae ? inv_batch / (float)h->D : inv_batch; f.l2 = d.l2;
+                f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
+                f.st = h->st; f.advance = d.advance ? 0 : 1;
+                { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
+            }
+            h->last_epoch_launches = launches;
+            return 0;
+        }
         DwArgs d{};
         const int t = small ? 32 : (big ? 128 : 64);
         int tb = 0;
@@ -798,34 +894,11 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             q.C = h->G + y.off; q.ldc = y.ld; q.fi = y.fi; q.fo = y.fo;
             q.tiles_n = (y.fo + t - 1) / t; q.tile_begin = tb;
             tb += ((y.fi + (small ? 1 : 0) + t - 1) / t) * q.tiles_n;
-            q.off = y.off; q.l2 = y.l2;
         }
         d.n_layers = NL; d.total_tiles = tb; d.rows = rows; d.splits = splits;
         d.k_per_split = (((rows + splits - 1) / splits) + 31) & ~31;
         d.slab_stride = h->P_int;
         if (!small) d.total_tiles = plan_dw_units(h, big, splits, &d, nullptr);      // (tile, K range) work units
-        // Small mini-batches, a full step, no dropout: the weight-gradient launch applies the update itself (small_gemm.hip:
-        // small_dw_opt) -- one launch fewer per mini-batch, no gradient slab, no optimizer sweep.
-        static const bool dwopt_env = []() { const char* e = std::getenv("SMRT_HIP_DW_OPT"); return e ? std::atoi(e) != 0 : true; }();
-        if (small && mode == 0 && !h->has_drop && dwopt_env && tb <= h->l2_cap) {
-            d.W = h->W; d.s0 = h->s0; d.s1 = h->s1; d.grad_out = o.grad_out; d.l2_partials = h->l2_p; d.st = h->st;
-            d.opt = h->cfg.optimizer; d.clip = h->cfg.clip; d.has_l2 = h->has_l2 ? 1 : 0;
-            d.lr = h->cfg.learning_rate; d.l2 = h->has_l2 ? h->cfg.l2_penalty : 0.f;
-            d.gmin = h->cfg.gclip_min; d.gmax = h->cfg.gclip_max;
-            d.advance = h->cfg.optimizer != 2;          // (as the sweep: under Adam every block reads the powers, finalize advances)
-            { ProfScope ps(h, PK_DW); launch_small_dw_opt(s, d); } ++launches;
-            h->img_valid = false;
-            if (o.cost_slot || !d.advance) {
-                FinalizeArgs f{};
-                f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p; f.n_l2 = tb;
-                f.inv_batch = h->ae ? inv_batch / (float)h->D : inv_batch; f.l2 = d.l2;
-                f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
-                f.st = h->st; f.advance = d.advance ? 0 : 1;
-                { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
-            }
-            h->last_epoch_launches = launches;
-            return 0;
-        }
         { ProfScope ps(h, PK_DW); if (small) launch_small_dw(s, d); else launch_dw(s, d, big); } ++launches;
     }
     if (mode == 1) {

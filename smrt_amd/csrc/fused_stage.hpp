@@ -81,46 +81,6 @@ __device__ __forceinline__ void k_chunk(const float* ap, const float* bp, int bs
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 
 
-// L2-free optimizer arithmetic of one element / of four (base.py:135-149, autoencoder.py:38-48); shared by every kernel that
-// applies an update in its epilogue.
-__device__ __forceinline__ float opt_apply(int opt, float lr, float alpha, float w, float g, float& s0, float& s1) {
-    switch (opt) {
-        case 1:     // RMSProp: decay .9, momentum 0, eps 1e-10 (rms slot starts at 1); v_rsq_f32 is 1 ulp
-            s0 = s0 + (g * g - s0) * (1.0f - 0.9f);
-            s1 = s1 * 0.0f + lr * g * __builtin_amdgcn_rsqf(s0 + 1e-10f);
-            return w - s1;
-        case 2:     // Adam
-            s0 = s0 + (g - s0) * (1.0f - 0.9f);
-            s1 = s1 + (g * g - s1) * (1.0f - 0.999f);
-            return w - alpha * s0 / (sqrtf(s1) + 1e-8f);
-        case 3: case 6:   // Adagrad / ProximalAdagrad(l1 = l2 = 0)
-            s0 = s0 + g * g;
-            return w - lr * g / sqrtf(s0);
-        case 4: {   // Adadelta: rho .95, eps 1e-8
-            s0 = s0 * 0.95f + g * g * (1.0f - 0.95f);
-            const float upd = sqrtf(s1 + 1e-8f) / sqrtf(s0 + 1e-8f) * g;
-            s1 = s1 * 0.95f + upd * upd * (1.0f - 0.95f);
-            return w - lr * upd;
-        }
-        default:    // SGD / ProximalGradientDescent(l1 = l2 = 0)
-            return w - lr * g;
-    }
-}
-
-// Four elements at once with ONE (uniform) switch around them.
-__device__ __forceinline__ void opt_apply4(int opt, float lr, float alpha, const float (&w)[4], const float (&g)[4],
-                                           float (&s0)[4], float (&s1)[4], float (&wn)[4]) {
-    switch (opt) {
-#define SMRT_OPT_CASE(K) _Pragma("unroll") for (int r = 0; r < 4; ++r) wn[r] = opt_apply(K, lr, alpha, w[r], g[r], s0[r], s1[r]); break
-        case 1: SMRT_OPT_CASE(1);
-        case 2: SMRT_OPT_CASE(2);
-        case 3: case 6: SMRT_OPT_CASE(3);
-        case 4: SMRT_OPT_CASE(4);
-        default: SMRT_OPT_CASE(0);
-#undef SMRT_OPT_CASE
-    }
-}
-
 // A stage's 16-byte output store: 0 none (everything stays in LDS), 1 plain global store (the next KERNEL reads it),
 // 2 write-through `sc1` store (another workgroup of the SAME launch reads it: cdna guide, Guideline 16, R1).
 template <int MODE>

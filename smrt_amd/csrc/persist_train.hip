@@ -32,11 +32,6 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned gu32;
 
 constexpr int AUX_SC1 = 16;             // buffer-instruction cache policy: sc1 = write-through store / L1-bypassing load
-constexpr unsigned RSRC_WORD3 = 0x00020000u;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, RSRC_WORD3);
-}
 __device__ __forceinline__ f32x4 load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AUX_SC1);
     return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};

@@ -37,28 +37,26 @@
 
 namespace smrt {
 
+// diagnostic builds (make stamps): phase time stamps (100 MHz wall clock) of the first workgroup and of one from the middle
+#ifdef SMRT_STAMPS
+#define SST(i) do { if (a.dbg && threadIdx.x == 0) { const unsigned b_ = blockIdx.y * gridDim.x + blockIdx.x, n_ = gridDim.x * gridDim.y; \
+    if (b_ == 0) a.dbg[i] = wall_clock64(); else if (b_ == n_ / 2) a.dbg[16 + (i)] = wall_clock64(); else if (b_ == n_ - 1) a.dbg[32 + (i)] = wall_clock64(); } } while (0)
+#else
+#define SST(i) do { } while (0)
+#endif
+
 constexpr int ST = 32;                 // output tile edge
-constexpr int SG = 8;                  // k-blocks per wave per batch (8 x 8 = 64 k)
 constexpr int SRED = 33;               // LDS row stride of a partial tile
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// The four k-step values of one 8-wide k-block for this lane (k = kb4 + s, s = 0..3; kb4 = block start + 4 h), loaded from a
-// clamped in-bounds address.  mask_kblock() then zeroes (or sets to one, for the virtual ones index of the bias gradient)
-// what lies outside the matrix -- LATER, when the values are about to be used: a select right behind the load would make the
-// wave wait for its prefetch before multiplying the batch it already has.
-template <int LAY>
-__device__ __forceinline__ f32x4v load_kblock(const float* __restrict__ g, long ld, int mn, int MN_data, int kb4, int K) {
-    if constexpr (LAY == INNER) {       // [mn][k], k contiguous: one 16-byte load
-        return *reinterpret_cast<const f32x4v*>(g + (long)min(mn, MN_data - 1) * ld + min(kb4, (int)ld - 4));
-    } else {                            // [k][mn], mn contiguous: four 4-byte loads, each 128 B contiguous per half-wave
-        const float* p = g + min(mn, MN_data - 1);
-        f32x4v v;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = p[(long)min(kb4 + s, K - 1) * ld];
-        return v;
-    }
-}
+// ------------------------------------------------------------------ 32x32 weight-gradient tiles on v_mfma_f32_32x32x2_f32
+// Both operands are mn-contiguous ([k][m] layer inputs, [k][n] gradients; k = row of the mini-batch): per 8-wide k-block a
+// lane takes four 4-byte loads per operand (k = block + 4 h + s at step s), each 128 B contiguous per half-wave.  The loads
+// are BUFFER loads: per-lane offset (4 h rows + the lane's column: one register per operand for the whole tile) + a uniform
+// offset per (block, step) in an SGPR, and rows past the mini-batch read as zero (the descriptor ends with the last row), so
+// a ragged K needs neither clamps nor masks.  What still needs a mask is an edge tile: columns past the matrix, and the
+// virtual ones index of the bias gradient.
 template <bool ONES>
 __device__ __forceinline__ f32x4v mask_kblock(f32x4v t, int mn, int MN_data, int kb4, int K) {
     const bool in = mn < MN_data;
@@ -69,9 +67,11 @@ __device__ __forceinline__ f32x4v mask_kblock(f32x4v t, int mn, int MN_data, int
     return v;
 }
 
-// One 32x32 tile of A.B over k in [0, K): returns this thread's four reduced outputs (row = tid >> 3, columns
-// 4 * (tid & 7) .. + 3 of the tile).  `red` = 4 * 32 * SRED floats of LDS.
-template <int ALAY, int BLAY, bool A_ONES>
+// One 32x32 tile of A^T.B over k in [0, K), A = [K][lda] (+ a virtual all-ones column at index M_data when A_ONES), B = [K][ldb]:
+// returns this thread's four reduced outputs (row = tid >> 3, columns 4 * (tid & 7) .. + 3 of the tile).
+// `red` = 4 * 32 * SRED floats of LDS.  SG 8-wide k-blocks per wave are in flight at a time (ONE batch: K up to 32 SG rows is a
+// single round trip), without a second buffer: the weight-gradient launch wants four workgroups a CU more than overlap.
+template <bool A_ONES, int SG>
 __device__ __forceinline__ f32x4v small_tile(const float* __restrict__ A, long lda, int M_data,
                                              const float* __restrict__ B, long ldb, int N_data,
                                              int m0, int n0, int K, float* red) {
@@ -83,46 +83,40 @@ __device__ __forceinline__ f32x4v small_tile(const float* __restrict__ A, long l
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const unsigned lda4 = (unsigned)lda * 4u, ldb4 = (unsigned)ldb * 4u;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(A, (unsigned)K * lda4), rb = make_rsrc(B, (unsigned)K * ldb4);
+    const unsigned va = 4u * (unsigned)h * lda4 + 4u * (unsigned)min(m0 + r, M_data - 1);
+    const unsigned vb = 4u * (unsigned)h * ldb4 + 4u * (unsigned)min(n0 + r, N_data - 1);
 
-    f32x4v fa[SG], fb[SG], na[SG], nb[SG];
-    auto fetch = [&](int first, f32x4v (&xa)[SG], f32x4v (&xb)[SG]) {
-#pragma unroll
-        for (int j = 0; j < SG; ++j) {
-            const int kb4 = ((first + j) * 4 + wave) * 8 + 4 * h;      // blocks past the end read a clamped address
-            xa[j] = load_kblock<ALAY>(A, lda, m0 + r, M_data, kb4, K);
-            xb[j] = load_kblock<BLAY>(B, ldb, n0 + r, N_data, kb4, K);
-        }
-    };
-    // interior tiles with K a multiple of 8 need no masking at all (wave-uniform)
-    const bool clean = (m0 + ST <= M_data) && (n0 + ST <= N_data) && ((K & 7) == 0);
-    auto mask = [&](int first, f32x4v (&xa)[SG], f32x4v (&xb)[SG]) {
-        if (clean) return;
-#pragma unroll
-        for (int j = 0; j < SG; ++j) {
-            const int kb4 = ((first + j) * 4 + wave) * 8 + 4 * h;
-            xa[j] = mask_kblock<A_ONES>(xa[j], m0 + r, M_data, kb4, K);
-            xb[j] = mask_kblock<false>(xb[j], n0 + r, N_data, kb4, K);
-        }
-    };
-    if (mine > 0) { fetch(0, fa, fb); mask(0, fa, fb); }
+    f32x4v fa[SG], fb[SG];
+    // interior tiles need no masking at all (wave-uniform); rows past K arrive as zeros
+    const bool clean = (m0 + ST <= M_data) && (n0 + ST <= N_data);
 #pragma unroll 1
-    for (int i = 0; i < mine; i += SG) {
-        const bool more = i + SG < mine;
-        if (more) fetch(i + SG, na, nb);
-        asm volatile("" ::: "memory");                   // next batch is requested before this one is multiplied
-        __builtin_amdgcn_sched_barrier(0);
-        const int cnt = min(SG, mine - i);
+    for (int i0 = 0; i0 < mine; i0 += SG) {
+#pragma unroll
+        for (int j = 0; j < SG; ++j) {
+            const unsigned row0 = (unsigned)(((i0 + j) * 4 + wave) * 8);      // (uniform) blocks past the end read zeros
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                fa[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, va, (row0 + s) * lda4, 0));
+                fb[j][s] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vb, (row0 + s) * ldb4, 0));
+            }
+        }
+        if (!clean) {
+#pragma unroll
+            for (int j = 0; j < SG; ++j) {
+                const int kb4 = ((i0 + j) * 4 + wave) * 8 + 4 * h;
+                fa[j] = mask_kblock<A_ONES>(fa[j], m0 + r, M_data, kb4, K);
+                fb[j] = mask_kblock<false>(fb[j], n0 + r, N_data, kb4, K);
+            }
+        }
+        const int cnt = min(SG, mine - i0);
 #pragma unroll
         for (int j = 0; j < SG; ++j) {
             if (j < cnt) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j][s], fb[j][s], acc, 0, 0, 0);
             }
-        }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < SG; ++j) { fa[j] = na[j]; fb[j] = nb[j]; }
-            mask(i + SG, fa, fb);
         }
     }
     // the four waves' partial tiles meet in LDS
@@ -203,10 +197,13 @@ __device__ __forceinline__ void mask16(KFrag<MT, NT>& f, int M_data, int N_data,
 
 // One (16 MT) x (16 NT) tile of A.B over k in [0, K): returns this thread's four reduced outputs -- row = tid / TPR, columns
 // 4 (tid % TPR) .. + 3 of the tile; meaningful for tid < ACTIVE.  `red` = TS<MT, NT>::RED floats of LDS.
-template <int BLAY, int MT, int NT>
+struct NoOverlap { __device__ __forceinline__ void operator()() const {} };
+// `overlap` runs between the request for the first batch of fragments and its first use: independent arithmetic put there
+// (the reparameterisation's Philox draw) hides under the fetch, which is most of a small tile's time.
+template <int BLAY, int MT, int NT, class Overlap = NoOverlap>
 __device__ __forceinline__ f32x4v small_tile16(const float* __restrict__ A, long lda, int M_data,
                                                const float* __restrict__ B, long ldb, int N_data,
-                                               int m0, int n0, int K, float* red) {
+                                               int m0, int n0, int K, float* red, Overlap overlap = Overlap()) {
     using T = TS<MT, NT>;
     constexpr int SG16 = T::SG;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -236,7 +233,11 @@ __device__ __forceinline__ f32x4v small_tile16(const float* __restrict__ A, long
         for (int j = 0; j < SG16; ++j)
             mask16<BLAY, MT, NT>(x[j], M_data, N_data, m0, n0, ((first + j) * 4 + wave) * 16 + 4 * q, K, i);
     };
-    if (mine > 0) { fetch(0, cur); mask(0, cur); }
+    if (mine > 0) fetch(0, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    overlap();
+    __builtin_amdgcn_sched_barrier(0);
+    if (mine > 0) mask(0, cur);
 #pragma unroll 1
     for (int b0 = 0; b0 < mine; b0 += SG16) {
         const bool more = b0 + SG16 < mine;
@@ -291,6 +292,10 @@ __device__ __forceinline__ f32x4v small_tile16(const float* __restrict__ A, long
 constexpr int SMALL_TILE_FILL = 200;
 static int forced_small_tile() {
     const char* e = std::getenv("SMRT_HIP_SMALL_TILE");               // (read per call: tests vary it)
+    return (e && *e) ? std::atoi(e) : 0;
+}
+static int forced_mid_tile() {
+    const char* e = std::getenv("SMRT_HIP_MID_TILE");
     return (e && *e) ? std::atoi(e) : 0;
 }
 int small_tile_shape(int M, int N) {
@@ -355,7 +360,9 @@ __device__ __forceinline__ void small_gemm_body(const GemmArgs& a, int tx, int t
             pe[c] = a.aux2[(long)rowc * a.ldaux2 + colc];
         }
     }
+    SST(0);
     const f32x4v v = small_tile16<BLAY, MT, NT>(a.A, a.lda, a.M, a.B, a.ldb, a.N, m0, n0, a.K, red);
+    SST(1);
     const bool rin = active && row < a.M;
     float lsum = 0.f;
     float o[4], o2[4];
@@ -525,7 +532,9 @@ __device__ __forceinline__ void mid_fwd_body(const MidArgs& a, int tx, int ty) {
         pb[c] = a.bh[min(c4 + c, N2 - 1)];
         pd[c] = a.bd[min(n0 + c42 + c, a.hL - 1)];
     }
-    // epsilon of this thread's reparameterisation elements, requested now (injected) -- up to 2 per thread (32 Z <= 512)
+    // epsilon of this thread's reparameterisation elements -- up to 2 per thread (32 Z <= 512): injected values are requested
+    // now; the Philox draw (indexed by step and row, ~150 instructions per element) runs while the heads tile's operands are
+    // on their way
     float pe[2] = {0.f, 0.f};
     if (a.eps_in) {
 #pragma unroll
@@ -536,8 +545,19 @@ __device__ __forceinline__ void mid_fwd_body(const MidArgs& a, int tx, int ty) {
         }
     }
     const uint32_t step = a.st->step;
+    SST(0);
+    auto draw = [&]() {
+        if (a.eps_in) return;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * 256;
+            const int r = e / Z, k = e - r * Z;
+            if (e < T::TM * Z) pe[u] = philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + m0 + r) * Z + k);
+        }
+    };
     // ---- heads: act(h . [W_mu | W_ls] + b)                                        layer.py:312-317
-    const f32x4v v = small_tile16<OUTER, MT, 2>(a.H, a.ldh, a.M, a.Wh, a.ldwh, N2, m0, 0, a.hL, red);
+    const f32x4v v = small_tile16<OUTER, MT, 2>(a.H, a.ldh, a.M, a.Wh, a.ldwh, N2, m0, 0, a.hL, red, draw);
+    SST(1);
     if (act1) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -558,7 +578,7 @@ __device__ __forceinline__ void mid_fwd_body(const MidArgs& a, int tx, int ty) {
             float z = 0.f, klv = 0.f;
             if (grow < a.M) {
                 const float mu = ml[r * MID_LD + k], ls = ml[r * MID_LD + Z + k];
-                const float ee = a.eps_in ? pe[u] : philox_normal1(a.seed, STREAM_EPS, step, (uint64_t)(a.row0_global + grow) * Z + k);
+                const float ee = pe[u];
                 z = mu + ee * expf(ls);
                 if (first) {
                     a.Zb[(long)grow * a.ldz + k] = z;
@@ -583,8 +603,10 @@ __device__ __forceinline__ void mid_fwd_body(const MidArgs& a, int tx, int ty) {
             if (l == 0 && sr * 16 < a.M) a.kl_partials[sr] = kl;
         }
     }
+    SST(2);
     // ---- first decoder layer, this workgroup's columns: act(z . W + b), z from LDS (K = Z)        layer.py:325-331
     const f32x4v v2 = small_tile16<OUTER, MT, NT>(zt, MID_LD, T::TM, a.Wd, a.ldwd, a.hL, 0, n0, Z, red);
+    SST(3);
     if (act2 && row2 < a.M) {
         float o[4];
 #pragma unroll
@@ -693,7 +715,10 @@ int mid_row_blocks(int rows, int hL) { (void)hL; return (rows + 15) / 16; }
 void launch_mid_fwd(hipStream_t s, const MidArgs& a0) {
     MidArgs a = a0;
     a.xmap = pick_xmap(a.M, a.hL);
-    const int sh = small_tile_shape(a.M, a.hL);
+    // (a mid workgroup's time is its heads / dz tile, whatever the width of its own columns: 16x32 tiles halve the
+    // workgroups that each recompute that tile, measured 46.6 -> 45.5 us per N1 mini-batch of 128 rows against 16x16)
+    const int fm = forced_mid_tile(), sa = small_tile_shape(a.M, a.hL);
+    const int sh = (fm == 22 || fm == 12 || fm == 11) ? fm : (sa == 11 ? 12 : sa);
     const dim3 grid((a.hL + shape_tn(sh) - 1) / shape_tn(sh), (a.M + shape_tm(sh) - 1) / shape_tm(sh));
     if (sh == 22)      SMRT_LAUNCH((mid_fwd_kernel<2, 2>), grid, dim3(256), 0, s, a);
     else if (sh == 12) SMRT_LAUNCH((mid_fwd_kernel<1, 2>), grid, dim3(256), 0, s, a);
@@ -702,7 +727,10 @@ void launch_mid_fwd(hipStream_t s, const MidArgs& a0) {
 void launch_mid_bwd(hipStream_t s, const MidArgs& a0) {
     MidArgs a = a0;
     a.xmap = pick_xmap(a.M, a.hL);
-    const int sh = small_tile_shape(a.M, a.hL);
+    // (a mid workgroup's time is its heads / dz tile, whatever the width of its own columns: 16x32 tiles halve the
+    // workgroups that each recompute that tile, measured 46.6 -> 45.5 us per N1 mini-batch of 128 rows against 16x16)
+    const int fm = forced_mid_tile(), sa = small_tile_shape(a.M, a.hL);
+    const int sh = (fm == 22 || fm == 12 || fm == 11) ? fm : (sa == 11 ? 12 : sa);
     const dim3 grid((a.hL + shape_tn(sh) - 1) / shape_tn(sh), (a.M + shape_tm(sh) - 1) / shape_tm(sh));
     if (sh == 22)      SMRT_LAUNCH((mid_bwd_kernel<2, 2>), grid, dim3(256), 0, s, a);
     else if (sh == 12) SMRT_LAUNCH((mid_bwd_kernel<1, 2>), grid, dim3(256), 0, s, a);
@@ -720,7 +748,7 @@ __device__ __forceinline__ void small_dw_body(const DwArgs& a) {
     const DwLayer& L = a.L[li];
     const int lt = t - L.tile_begin;
     const int m0 = (lt / L.tiles_n) * ST, n0 = (lt % L.tiles_n) * ST;
-    const f32x4v v = small_tile<OUTER, OUTER, true>(L.A, L.lda, L.fi, L.B, L.ldb, L.fo, m0, n0, a.rows, red);
+    const f32x4v v = small_tile<true, 8>(L.A, L.lda, L.fi, L.B, L.ldb, L.fo, m0, n0, a.rows, red);
     const int row = m0 + (threadIdx.x >> 3), col0 = n0 + (threadIdx.x & 7) * 4;
     if (row <= L.fi) {                                   // row == fi is the bias gradient
         float* dst = L.C + (long)row * L.ldc + col0;     // ldc % 4 == 0 and col0 % 4 == 0: aligned
@@ -751,20 +779,20 @@ void launch_small_dw(hipStream_t s, const DwArgs& a) {
 // its own, mostly its floor) is gone from the step.  The tile's weights and both slots are REQUESTED BEFORE the main loop,
 // 16 bytes per thread from clamped addresses, so they arrive under it.  (Round 2 tried this with the slot loads behind the
 // reduction: 19 us against 10 + 7.)  Same arithmetic as the sweep (opt_update_ieee), same bits.
-__device__ __forceinline__ void small_dw_opt_body(const DwArgs& a) {
+template <int SGB>
+__device__ __forceinline__ void small_dw_opt_body(const DwFusedArgs& a) {
     __shared__ float red[4 * ST * SRED];
     __shared__ float sred[4];
     const int tid = threadIdx.x;
     const int t = blockIdx.x;
-    int li = 0;
-#pragma unroll 1
-    for (int i = 1; i < a.n_layers; ++i) if (t >= a.L[i].tile_begin) li = i;
-    const DwLayer& L = a.L[li];
-    const int lt = t - L.tile_begin;
-    const int m0 = (lt / L.tiles_n) * ST, n0 = (lt % L.tiles_n) * ST;
+    SST(0);
+    const DwRec L = a.tiles[t];                                          // (uniform index: one scalar load)
+    const float* A = L.A ? L.A : a.X;
+    const long lda = L.A ? (long)L.lda : a.ldx;
+    const int m0 = L.m0, n0 = L.n0;
     const int row = m0 + (tid >> 3), col0 = n0 + (tid & 7) * 4;
-    const bool inq = row <= L.fi && col0 < (int)L.ldc;               // this thread's quad exists (row == fi: the bias)
-    const long ix = L.off + (long)min(row, L.fi) * L.ldc + min(col0, (int)L.ldc - 4);
+    const bool inq = row <= L.fi && col0 < L.ldc;                         // this thread's quad exists (row == fi: the bias)
+    const long ix = L.off + (long)min(row, L.fi) * L.ldc + min(col0, L.ldc - 4);
     const float4 w4 = *reinterpret_cast<const float4*>(a.W + ix);
     const float4 s04 = *reinterpret_cast<const float4*>(a.s0 + ix);
     const float4 s14 = *reinterpret_cast<const float4*>(a.s1 + ix);
@@ -777,7 +805,13 @@ __device__ __forceinline__ void small_dw_opt_body(const DwArgs& a) {
         a.st->b1pow *= 0.9f;
         a.st->b2pow *= 0.999f;
     }
-    const f32x4v v = small_tile<OUTER, OUTER, true>(L.A, L.lda, L.fi, L.B, L.ldb, L.fo, m0, n0, a.rows, red);
+    SST(1);
+    // (ONE batch of eight 8-wide k-blocks in flight: mini-batches up to 256 rows are a single round trip per wave, and without
+    // the second buffer the kernel stays under 128 VGPRs -- four workgroups a CU, so that N1's 780 tiles are all resident at
+    // once; with 163 VGPRs three were, the last 12 tiles started when the first ones had finished, and the launch took two
+    // tile times instead of one)
+    const f32x4v v = small_tile<true, SGB>(A, lda, L.fi, L.B, L.ldb, L.fo, m0, n0, a.rows, red);
+    SST(2);
     float l2acc = 0.f;
     if (inq) {
         float gv[4] = {v[0], v[1], v[2], v[3]};
@@ -793,30 +827,225 @@ __device__ __forceinline__ void small_dw_opt_body(const DwArgs& a) {
         if (a.grad_out) *reinterpret_cast<float4*>(a.grad_out + ix) = make_float4(gv[0], gv[1], gv[2], gv[3]);
         const bool has_s0 = a.opt != 0 && a.opt != 5;
         const bool has_s1 = a.opt == 1 || a.opt == 2 || a.opt == 4;
+        float gc[4], wn[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float gj = gv[j];
-            if (a.clip) gj = tf_clip(gj, a.gmin, a.gmax);           // tf.clip_by_value, base.py:144
-            wv[j] = opt_update_ieee(a.opt, a.lr, alpha, wv[j], gj, s0v[j], s1v[j]);
-        }
+        for (int j = 0; j < 4; ++j) gc[j] = a.clip ? tf_clip(gv[j], a.gmin, a.gmax) : gv[j];      // tf.clip_by_value, base.py:144
+        // (opt_apply4: v_rsq_f32 / v_rcp-free forms, 1 ulp, as the LDS-resident kernels' epilogues -- four workgroups a CU
+        // run this phase in lockstep, so its instruction count is paid four times over)
+        opt_apply4(a.opt, a.lr, alpha, wv, gc, s0v, s1v, wn);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = wn[j];
         *reinterpret_cast<float4*>(a.W + ix) = make_float4(wv[0], wv[1], wv[2], wv[3]);
         if (has_s0) *reinterpret_cast<float4*>(a.s0 + ix) = make_float4(s0v[0], s0v[1], s0v[2], s0v[3]);
         if (has_s1) *reinterpret_cast<float4*>(a.s1 + ix) = make_float4(s1v[0], s1v[1], s1v[2], s1v[3]);
+    }
+    SST(3);
+#ifdef SMRT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SST(4);
+#endif
+    if (a.want_l2) {                                                 // (uniform) only the steps whose cost is read
+        const float tot = block_sum_256(l2acc, sred);
+        if (tid == 0) a.l2_partials[t] = tot;
+    }
+    SST(5);
+}
+
+template <int SGB> __global__ __launch_bounds__(256, 4) void small_dw_opt_kernel(const DwFusedArgs a) { small_dw_opt_body<SGB>(a); }
+template <int SGB> __global__ __launch_bounds__(256, 4) void small_dw_opt_multi(const MultiSlot<DwFusedArgs>* __restrict__ t) {
+    const MultiSlot<DwFusedArgs>& s = t[blockIdx.z];
+    if (blockIdx.x >= s.gx) return;
+    small_dw_opt_body<SGB>(s.a);
+}
+static MultiReg<DwFusedArgs> reg_small_dw_opt4(small_dw_opt_kernel<4>, small_dw_opt_multi<4>);
+static MultiReg<DwFusedArgs> reg_small_dw_opt8(small_dw_opt_kernel<8>, small_dw_opt_multi<8>);
+
+// (the batch is sized to the mini-batch: up to 128 rows are four k-blocks per wave, up to 256 eight -- loads past the end
+// would return zeros, but they would still be issued)
+void launch_small_dw_opt(hipStream_t s, const DwFusedArgs& a) {
+    if (a.rows <= 128) SMRT_LAUNCH(small_dw_opt_kernel<4>, dim3(a.total_tiles), dim3(256), 0, s, a);
+    else               SMRT_LAUNCH(small_dw_opt_kernel<8>, dim3(a.total_tiles), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------ the same launch on 64x64 tiles
+// 780 tiles of 32x32 re-read every operand panel 25 / 15 times: 25 MB of activations and gradients through the CUs' L1s
+// for 2.9 MB of weights, three workgroups a CU.  A 64x64 tile halves that traffic and N1's 224 tiles are one workgroup per
+// CU.  v_mfma_f32_16x16x4_f32 with BOTH operands mn-contiguous ([k][m] inputs, [k][n] gradients): lane i loads four
+// consecutive m (n) of row k = block + 4 q + s as ONE 16-byte load (16 lanes x 16 bytes contiguous) and accumulator
+// (mt, nt) holds rows m0 + 4 (4 q + r) + mt, columns n0 + 4 i + nt -- the interleave is undone when the four waves' partial
+// tiles (K split by k-block, as everywhere here) meet in LDS.  The tile's weights and slots are requested between the
+// last MFMA and that reduction.  Chosen when the net has at least DW64_MIN_TILES such tiles (smaller nets keep the
+// parallelism of 32x32 tiles).
+constexpr int DW64 = 64, DW64_RS = 65, DW64_SG = 2;
+struct Frag64 { f32x4v a[4], b[4]; };        // [k step]: four consecutive m / n of row k4 + s
+
+__device__ __forceinline__ void small_dw64_opt_body(const DwFusedArgs& a) {
+    extern __shared__ float red64[];                                  // 4 x 64 x DW64_RS floats
+    __shared__ float sred[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int t = blockIdx.x;
+    const DwRec L = a.tiles[t];                                          // (uniform index: one scalar load)
+    const float* Ap = L.A ? L.A : a.X;
+    const long lda = L.A ? (long)L.lda : a.ldx;
+    const int m0 = L.m0, n0 = L.n0;
+    const int K = a.rows, fi = L.fi, fo = L.fo;
+    float alpha = 0.f;
+    if (a.opt == 2) alpha = a.lr * sqrtf(1.0f - a.st->b2pow) / (1.0f - a.st->b1pow);
+    if (a.advance && t == 0 && tid == 0) {       // (never under Adam, whose blocks all read the beta powers above)
+        a.st->step += 1;
+        a.st->b1pow *= 0.9f;
+        a.st->b2pow *= 0.999f;
+    }
+    const int nkb = (K + 15) >> 4;
+    const int mine = (nkb - wave + 3) >> 2;
+    // this lane's four m / four n; loads come from clamped, always-valid quads (a row of the operand is a multiple of 4 long)
+    const int mq = m0 + 4 * i, nq = n0 + 4 * i;
+    const float* pa = Ap + min(mq, (int)lda - 4);
+    const float* pb = L.B + min(nq, L.ldb - 4);
+    const bool edge = (m0 + DW64 > fi) || (n0 + DW64 > fo) || ((K & 15) != 0);     // (the ones row makes every last row tile an edge)
+    f32x4v acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    Frag64 cur[DW64_SG], nxt[DW64_SG];
+    auto fetch = [&](int first, Frag64 (&x)[DW64_SG]) {
+#pragma unroll
+        for (int j = 0; j < DW64_SG; ++j) {
+            const int k4 = ((first + j) * 4 + wave) * 16 + 4 * q;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const long r = (long)min(k4 + s2, K - 1);
+                x[j].a[s2] = *reinterpret_cast<const f32x4v*>(pa + r * lda);
+                x[j].b[s2] = *reinterpret_cast<const f32x4v*>(pb + r * L.ldb);
+            }
+        }
+    };
+    auto mask = [&](int first, Frag64 (&x)[DW64_SG]) {
+        if (!edge) return;
+#pragma unroll
+        for (int j = 0; j < DW64_SG; ++j) {
+            const int k4 = ((first + j) * 4 + wave) * 16 + 4 * q;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const bool kin = k4 + s2 < K;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int m = mq + c, n = nq + c;
+                    x[j].a[s2][c] = kin ? (m < fi ? x[j].a[s2][c] : (m == fi ? 1.f : 0.f)) : 0.f;     // m == fi: the ones index (bias)
+                    x[j].b[s2][c] = (kin && n < fo) ? x[j].b[s2][c] : 0.f;
+                }
+            }
+        }
+    };
+    if (mine > 0) { fetch(0, cur); mask(0, cur); }
+#pragma unroll 1
+    for (int b0 = 0; b0 < mine; b0 += DW64_SG) {
+        const bool more = b0 + DW64_SG < mine;
+        if (more) fetch(b0 + DW64_SG, nxt);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const int cnt = min(DW64_SG, mine - b0);
+#pragma unroll
+        for (int j = 0; j < DW64_SG; ++j) {
+            if (j < cnt) {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[j].a[s2][mt], cur[j].b[s2][nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < DW64_SG; ++j) cur[j] = nxt[j];
+            mask(b0 + DW64_SG, cur);
+        }
+    }
+    // the tile's weights and slots: four quads per thread (quad e = tid + 256 u: row e / 16, columns 4 (e % 16) ..), requested
+    // now so that they arrive under the reduction
+    float4 w4[4], s04[4], s14[4];
+    long ix[4];
+    bool inq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + 256 * u, row = m0 + (e >> 4), col0 = n0 + (e & 15) * 4;
+        inq[u] = row <= fi && col0 < L.ldc;
+        ix[u] = L.off + (long)min(row, fi) * L.ldc + min(col0, L.ldc - 4);
+        w4[u] = *reinterpret_cast<const float4*>(a.W + ix[u]);
+        s04[u] = *reinterpret_cast<const float4*>(a.s0 + ix[u]);
+        s14[u] = *reinterpret_cast<const float4*>(a.s1 + ix[u]);
+    }
+    float* mine_red = red64 + wave * (DW64 * DW64_RS);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mine_red[(4 * (4 * q + r) + mt) * DW64_RS + 4 * i + nt] = acc[mt][nt][r];
+    __syncthreads();
+    const bool has_s0 = a.opt != 0 && a.opt != 5;
+    const bool has_s1 = a.opt == 1 || a.opt == 2 || a.opt == 4;
+    float l2acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = tid + 256 * u, lr = e >> 4, c4 = (e & 15) * 4, row = m0 + lr;
+        float gv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float* p = red64 + lr * DW64_RS + c4 + c;
+            gv[c] = (p[0] + p[DW64 * DW64_RS]) + (p[2 * DW64 * DW64_RS] + p[3 * DW64 * DW64_RS]);
+        }
+        if (inq[u]) {
+            float wv[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
+            float s0v[4] = {s04[u].x, s04[u].y, s04[u].z, s04[u].w}, s1v[4] = {s14[u].x, s14[u].y, s14[u].z, s14[u].w};
+            if (a.has_l2 && L.l2 && row < fi) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    gv[c] += a.l2 * wv[c];                               // tf.nn.l2_loss on the layer's weights, base.py:129
+                    l2acc += 0.5f * wv[c] * wv[c];
+                }
+            }
+            if (a.grad_out) *reinterpret_cast<float4*>(a.grad_out + ix[u]) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float gj = gv[c];
+                if (a.clip) gj = tf_clip(gj, a.gmin, a.gmax);           // tf.clip_by_value, base.py:144
+                wv[c] = opt_update_ieee(a.opt, a.lr, alpha, wv[c], gj, s0v[c], s1v[c]);
+            }
+            *reinterpret_cast<float4*>(a.W + ix[u]) = make_float4(wv[0], wv[1], wv[2], wv[3]);
+            if (has_s0) *reinterpret_cast<float4*>(a.s0 + ix[u]) = make_float4(s0v[0], s0v[1], s0v[2], s0v[3]);
+            if (has_s1) *reinterpret_cast<float4*>(a.s1 + ix[u]) = make_float4(s1v[0], s1v[1], s1v[2], s1v[3]);
+        }
     }
     const float tot = block_sum_256(l2acc, sred);
     if (tid == 0) a.l2_partials[t] = tot;
 }
 
-__global__ __launch_bounds__(256, 2) void small_dw_opt_kernel(const DwArgs a) { small_dw_opt_body(a); }
-__global__ __launch_bounds__(256, 2) void small_dw_opt_multi(const MultiSlot<DwArgs>* __restrict__ t) {
-    const MultiSlot<DwArgs>& s = t[blockIdx.z];
+__global__ __launch_bounds__(256, 2) void small_dw64_opt_kernel(const DwFusedArgs a) { small_dw64_opt_body(a); }
+__global__ __launch_bounds__(256, 2) void small_dw64_opt_multi(const MultiSlot<DwFusedArgs>* __restrict__ t) {
+    const MultiSlot<DwFusedArgs>& s = t[blockIdx.z];
     if (blockIdx.x >= s.gx) return;
-    small_dw_opt_body(s.a);
+    small_dw64_opt_body(s.a);
 }
-static MultiReg<DwArgs> reg_small_dw_opt(small_dw_opt_kernel, small_dw_opt_multi);
-
-void launch_small_dw_opt(hipStream_t s, const DwArgs& a) {
-    SMRT_LAUNCH(small_dw_opt_kernel, dim3(a.total_tiles), dim3(256), 0, s, a);
+static MultiReg<DwFusedArgs> reg_small_dw64_opt(small_dw64_opt_kernel, small_dw64_opt_multi);
+constexpr int DW64_LDS = 4 * DW64 * DW64_RS * (int)sizeof(float);
+static int dw64_lds_ready() {
+    static const int rc = []() {
+        int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(small_dw64_opt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW64_LDS);
+        if (r == 0) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(small_dw64_opt_multi), hipFuncAttributeMaxDynamicSharedMemorySize, DW64_LDS);
+        if (r != 0) (void)hipGetLastError();
+        return r;
+    }();
+    return rc;
+}
+bool small_dw64_available() { return dw64_lds_ready() == 0; }
+void launch_small_dw64_opt(hipStream_t s, const DwFusedArgs& a) {
+    SMRT_LAUNCH(small_dw64_opt_kernel, dim3(a.total_tiles), dim3(256), (size_t)DW64_LDS, s, a);
 }
 
 }  // namespace smrt

@@ -160,9 +160,6 @@ struct DwLayer {
     // last row of tiles / corner -- decides into how many K ranges it is cut (see plan_dw_units in api.hip)
     int tiles_m;
     int s_cls[4];
-    // fused weight-gradient + update launch (small_gemm.hip: small_dw_opt) only
-    long off;            // start of the layer's augmented matrix in the flat parameter / slot buffers
-    int l2, pad_;        // the layer is regularised (the heads are not, layer.py:96)
 };
 struct DwArgs {
     DwLayer L[MAX_LAYERS];
@@ -170,13 +167,31 @@ struct DwArgs {
     int rows, k_per_split, splits;
     long slab_stride;
     int ycum[33];        // tiled kernel: work units in front of K-range index y (units are ordered range-major)
-    // fused weight-gradient + update launch only: a tile's owner applies L2, clip and the optimizer to its 32x32 elements
+};
+
+// Fused weight-gradient + update launch of small mini-batches (small_gemm.hip: small_dw_opt / small_dw64_opt): one record
+// per output tile, built once per workspace (api.hip: ensure_train), read by its workgroup with ONE 64-byte scalar load.
+struct DwRec {
+    const float* A;      // layer input [rows][lda]; NULL: the mini-batch itself (DwFusedArgs::X, ldx), which moves every step
+    const float* B;      // dPre [rows][ldb]
+    long off;            // start of the layer's augmented matrix [fan_in + 1][ldc] in the flat parameter / slot buffers
+    int fi, fo;
+    int lda, ldb, ldc;
+    int m0, n0;          // tile origin (fan-in row, fan-out column)
+    int l2, pad_;        // the layer is regularised (the heads are not, layer.py:96)
+};
+static_assert(sizeof(DwRec) == 64, "DwRec is read as one 64-byte record");
+struct DwFusedArgs {
+    const DwRec* tiles; int total_tiles, rows;
+    const float* X; long ldx;
     float* W; float* s0; float* s1;
     float* grad_out;     // optional: pre-clip gradient wrt the variables (internal layout)
     float* l2_partials;  // one per tile
     DevState* st;
     int opt, clip, has_l2, advance;
+    int want_l2, pad_;   // the step's cost is read: leave the L2 partial sums (one per tile) for finalize
     float lr, l2, gmin, gmax;
+    unsigned long long* dbg;   // diagnostic builds only (-DSMRT_STAMPS)
 };
 
 struct OptSeg {
@@ -240,6 +255,7 @@ struct MidArgs {
     float inv_batch;
     uint64_t seed; const DevState* st; long row0_global;
     int xmap, pad_;                                  // workgroup -> tile map (small_gemm.hip: xcd_tile)
+    unsigned long long* dbg;                         // diagnostic builds only (-DSMRT_STAMPS)
 };
 void launch_mid_fwd(hipStream_t s, const MidArgs& a);
 void launch_mid_bwd(hipStream_t s, const MidArgs& a);
@@ -381,7 +397,9 @@ void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a);
 void launch_small_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a);
 int  small_gemm_blocks(const GemmArgs& a);
 void launch_small_dw(hipStream_t s, const DwArgs& a);
-void launch_small_dw_opt(hipStream_t s, const DwArgs& a);
+void launch_small_dw_opt(hipStream_t s, const DwFusedArgs& a);
+void launch_small_dw64_opt(hipStream_t s, const DwFusedArgs& a);     // the same on 64x64 tiles
+bool small_dw64_available();
 int  gemm_grid_blocks(int kind, const GemmArgs& a);          // number of blocks (= BCE partial count)
 void launch_dw(hipStream_t s, const DwArgs& a, bool big);
 void launch_optimizer(hipStream_t s, const OptArgs& a, int* n_blocks_out);

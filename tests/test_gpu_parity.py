@@ -271,6 +271,14 @@ def test_bce_saturation_matches_ieee():
         c_o = o.train_step(X.copy(), eps)
     c_h = h.train_step(X, eps)
     assert (np.isnan(c_o) and np.isnan(c_h)) or (np.isinf(c_o) and np.isinf(c_h) and np.sign(c_o) == np.sign(c_h)), (c_o, c_h)
+    # ... and what the step leaves behind: inf * 0 in the output layer is a NaN gradient, which tf.clip_by_value hands on
+    # (std::max / std::min keep a NaN first argument; fmaxf / fminf would turn it into +-5): the same parameters are NaN on
+    # both sides, the others agree, and the next step's cost is NaN
+    p_h, p_o = h.get_params(), flatten_params(o.params)
+    assert np.isnan(p_o).any() and np.array_equal(np.isnan(p_h), np.isnan(p_o)), (p_h, p_o)
+    np.testing.assert_allclose(p_h[~np.isnan(p_o)], p_o[~np.isnan(p_o)], rtol=RTOL, atol=1e-6)
+    with np.errstate(all="ignore"):
+        assert np.isnan(o.train_step(X.copy(), eps)) and np.isnan(h.train_step(X, eps))
     h.close()
     # lower clip: p underflows to < eps -> log(eps), zero gradient through the clip
     o2 = _oracle(D, hidden, Z, act="identity", opt="sgd", l2=None)
