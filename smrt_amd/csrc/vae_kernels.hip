@@ -7,6 +7,8 @@
 //   KL divergence + its gradient                               smrt/autoencode/_ae_utils.py:35-49
 //   L2 penalty, value clip, optimizer.apply_gradients          smrt/autoencode/base.py:127-149
 #include "vae_kernels.hpp"
+
+#include <cstdlib>
 #include "device_utils.hpp"
 #include "gemm_mfma_f32.hpp"
 
@@ -314,8 +316,23 @@ static void launch_gemm_t(hipStream_t s, const GemmArgs& a) {
     }
 }
 
+// Skinny layers of a large mini-batch: the latent heads (h -> 2 Z) and the first decoder layer's backward product
+// (dz = dPre . W^T, h -> Z) are one pass over a [rows x h] matrix into <= 32 columns.  The LDS-tiled kernel walks them as
+// 64-wide tiles that are mostly padding; the register-fed 16-row tiles (small_gemm.hip) take them straight from global
+// memory, whatever M is.  Measured on N1 at 8 192 rows (rocprofv3, us per launch, LDS-tiled -> register-fed): heads forward
+// 18.5 -> 12.8, dz + latent epilogue 19.2 -> 9.7.  NOT the K <= 32 products (first decoder layer forward 11.3 -> 12.8, heads
+// backward 10.4 -> 24.5: their 450-wide outputs are 15 column tiles of two k-blocks each), and not beyond 32 768 rows, where
+// the LDS-tiled kernel's longer-lived workgroups stream better (65 536 rows: 36 -> 49).  Not the output layer either (its
+// loss partials are counted per tile of the kernel that runs it).
+static bool skinny_gemm(int epi, const GemmArgs& a) {
+    static const int mode = []() { const char* e = std::getenv("SMRT_HIP_SKINNY"); return e ? std::atoi(e) : 1; }();
+    static const int max_m = []() { const char* e = std::getenv("SMRT_HIP_SKINNY_MAXM"); return e ? std::atoi(e) : 32768; }();
+    if (!mode || epi == EPI_BCE || epi == EPI_MSE || a.M > max_m) return false;
+    return a.N <= 32 || (mode == 2 && a.K <= 32);
+}
+
 void launch_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a) {
-    if (a.M <= SMALL_M_MAX) { launch_small_gemm(s, kind, epi, a); return; }
+    if (a.M <= SMALL_M_MAX || skinny_gemm(epi, a)) { launch_small_gemm(s, kind, epi, a); return; }
     if (kind == GEMM_NN) {
         if (epi == EPI_BIAS_ACT)         launch_gemm_t<INNER, OUTER, EPI_BIAS_ACT>(s, a);
         else if (epi == EPI_BCE)         launch_gemm_t<INNER, OUTER, EPI_BCE>(s, a);
