@@ -15,6 +15,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 namespace smrt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -211,31 +213,25 @@ __device__ __forceinline__ void gemm_tile_impl(const float* __restrict__ A, long
     // tile t+1 go into the other image, so one barrier per K-tile suffices (the image being overwritten was last
     // read before the previous barrier).
     constexpr int SZA = lds_floats<ALAY, BM>(), SZB = lds_floats<BLAY, BN>();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
-        const bool more = (k0 + BK) < kend;
-        if (more) {
-            const bool fk = (k0 + 2 * BK <= kend);
-            sa.load(A, lda, m0, M_data, k0 + BK, kend, tid, fullA && fk);
-            sb.load(B, ldb, n0, N_data, k0 + BK, kend, tid, fullB && fk);
-        }
-        const float* la = ldsA + buf * SZA;
-        const float* lb = ldsB + buf * SZB;
-        // Fragments of k-block kb+1 are requested before the MFMAs of k-block kb; the asm (which the tile addresses
-        // escape into, so its memory clobber covers them) and the scheduling barrier pin that order.  Left alone,
-        // hipcc sinks each LDS read to just before its MFMA and every group of MFMAs waits out a full LDS latency.
-        constexpr int FI = ARR == 0 ? WM : (LI > 0 ? LI : 1), FJ = ARR == 0 ? WN : (LJ > 0 ? LJ : 1);
-        const int abase = ARR == 0 ? wr * 32 * WM : (ARR == 1 ? wave * 32 : 0);
-        const int bbase = ARR == 0 ? wc * 32 * WN : (ARR == 2 ? wave * 32 : 0);
+    constexpr int FI = ARR == 0 ? WM : (LI > 0 ? LI : 1), FJ = ARR == 0 ? WN : (LJ > 0 ? LJ : 1);
+    const int abase = ARR == 0 ? wr * 32 * WM : (ARR == 1 ? wave * 32 : 0);
+    const int bbase = ARR == 0 ? wc * 32 * WN : (ARR == 2 ? wave * 32 : 0);
+    // The MFMAs of one K-tile image, NKB of its four 8-wide k-blocks (compile-time: the last K-tile of K = 450 holds two real
+    // k, of K = 784 sixteen -- multiplying its zero padding was 5 % / 2 % of those layers' matrix time).
+    // Fragments of k-block kb+1 are requested before the MFMAs of k-block kb; the asm (which the tile addresses
+    // escape into, so its memory clobber covers them) and the scheduling barrier pin that order.  Left alone,
+    // hipcc sinks each LDS read to just before its MFMA and every group of MFMAs waits out a full LDS latency.
+    auto multiply = [&](auto nkb_c, const float* la, const float* lb) {
+        constexpr int NKB = decltype(nkb_c)::value;
         float fa[2][FI][4], fb[2][FJ][4];
 #pragma unroll
         for (int i = 0; i < FI; ++i) read_frag<ALAY, BM>(la, abase + i * 32, 0, r, h, fa[0][i]);
 #pragma unroll
         for (int j = 0; j < FJ; ++j) read_frag<BLAY, BN>(lb, bbase + j * 32, 0, r, h, fb[0][j]);
 #pragma unroll
-        for (int kb = 0; kb < BK / 8; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             const int cur = kb & 1, nxt = cur ^ 1;
-            if (kb + 1 < BK / 8) {
+            if (kb + 1 < NKB) {
 #pragma unroll
                 for (int i = 0; i < FI; ++i) read_frag<ALAY, BM>(la, abase + i * 32, kb + 1, r, h, fa[nxt][i]);
 #pragma unroll
@@ -253,15 +249,27 @@ __device__ __forceinline__ void gemm_tile_impl(const float* __restrict__ A, long
                         d = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][s], fb[cur][j][s], d, 0, 0, 0);
                     }
         }
-        if (more) {
-            const bool fk = (k0 + 2 * BK <= kend);
-            sa.mask(m0, M_data, k0 + BK, kend, tid, fullA && fk);
-            sb.mask(n0, N_data, k0 + BK, kend, tid, fullB && fk);
-            sa.store(ldsA + (buf ^ 1) * SZA, tid);
-            sb.store(ldsB + (buf ^ 1) * SZB, tid);
-            if (bsum) sb.add_to(*bsum);
-            __syncthreads();
-        }
+    };
+    int buf = 0, k0 = kbeg;
+    for (; k0 + BK < kend; k0 += BK, buf ^= 1) {         // every K-tile but the last: stage the next one around the MFMAs
+        const bool fk = (k0 + 2 * BK <= kend);
+        sa.load(A, lda, m0, M_data, k0 + BK, kend, tid, fullA && fk);
+        sb.load(B, ldb, n0, N_data, k0 + BK, kend, tid, fullB && fk);
+        multiply(std::integral_constant<int, BK / 8>{}, ldsA + buf * SZA, ldsB + buf * SZB);
+        sa.mask(m0, M_data, k0 + BK, kend, tid, fullA && fk);
+        sb.mask(n0, N_data, k0 + BK, kend, tid, fullB && fk);
+        sa.store(ldsA + (buf ^ 1) * SZA, tid);
+        sb.store(ldsB + (buf ^ 1) * SZB, tid);
+        if (bsum) sb.add_to(*bsum);
+        __syncthreads();
+    }
+    {                                                    // the last K-tile: only its k-blocks that hold a real k (uniform)
+        const int nkb = (kend - k0 + 7) >> 3;
+        const float* la = ldsA + buf * SZA;
+        const float* lb = ldsB + buf * SZB;
+        if (nkb == 1)      multiply(std::integral_constant<int, 1>{}, la, lb);
+        else if (nkb == 2) multiply(std::integral_constant<int, 2>{}, la, lb);
+        else               multiply(std::integral_constant<int, BK / 8>{}, la, lb);
     }
 }
 
