@@ -106,6 +106,8 @@ struct smrt_vae {
     float* Wimg = nullptr;           // LDS-image twin of the parameters (fplan.img_total floats)
     bool img_valid = false;          // Wimg matches W (kept current by the fused optimizer epilogue)
     DwTile* tile_tab = nullptr;      // per-tile records of the fused dW + optimizer kernel
+    StageU* stage_u = nullptr;       // the persistent kernel's stage records, decoded (ensure_train)
+    int n_stage_u = 0;
     DwRec* dwrec = nullptr;          // small-batch fused weight-gradient + update launch: 32x32 tile records, then 64x64 ones
     int n_rec32 = 0, n_rec64 = 0;
     // persistent whole-epoch kernel (persist_train.hip)
@@ -411,6 +413,7 @@ static int fused_slab_splits(int rows) {
     return std::max(1, std::min(32, nblk / 8));
 }
 
+static int build_stages(const smrt_vae* h, const FusedArgs& f, FusedStage* stages);
 static int ensure_train(smrt_vae* h, int rows) {
     int splits = choose_splits(h, rows);
     if (h->fused && rows > 512 && rows <= FUSED_ROWS_MAX) splits = std::max(splits, fused_slab_splits(rows));
@@ -442,6 +445,7 @@ static int ensure_train(smrt_vae* h, int rows) {
             carve(a, &h->XT, (size_t)cap * rup16(h->D));
             carve(a, &h->ZT, (size_t)cap * rup16(h->Z));
             carve(a, &h->tile_tab, (size_t)h->tiles16);
+            carve(a, &h->stage_u, (size_t)(2 * MAX_LAYERS + 1));
         }
     };
     h->n_rec32 = h->n_rec64 = 0;
@@ -490,6 +494,23 @@ static int ensure_train(smrt_vae* h, int rows) {
         }
         if ((int)tiles.size() != h->tiles16) return fail(-4, "internal: tile table size mismatch");
         HIPC(hipMemcpy(h->tile_tab, tiles.data(), tiles.size() * sizeof(DwTile), hipMemcpyHostToDevice));
+        // the persistent kernel's stage records, decoded here once (they name workspace buffers: rebuilt with them)
+        FusedStage st[2 * MAX_LAYERS];
+        StageU su[2 * MAX_LAYERS + 1];
+        const int ns = build_stages(h, h->fplan, st);
+        for (int i = 0; i < ns; ++i) {
+            const FusedStage& t = st[i];
+            StageU& u = su[i];
+            u.in_off = t.in_off; u.sin = t.sin; u.nb_all = t.K16 >> 4; u.w_off = t.w_off;
+            u.nn = t.nn; u.N = t.N; u.packed = t.kind | (t.act << 8) | (t.trans << 16) | (t.variant << 24); u.N16 = rup16(t.N);
+            u.out_off = t.out_off; u.s_out = t.s_out; u.b_off = t.b_off; u.aux_off = t.aux_off;
+            u.s_aux = t.s_aux; u.NF16 = t.NF * 16;
+            const unsigned long long gp = (unsigned long long)(uintptr_t)t.gout;
+            u.gout_lo = (int)(unsigned)(gp & 0xffffffffull); u.gout_hi = (int)(unsigned)(gp >> 32);
+        }
+        su[ns] = su[ns - 1];
+        h->n_stage_u = ns;
+        HIPC(hipMemcpy(h->stage_u, su, (size_t)(ns + 1) * sizeof(StageU), hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -549,6 +570,7 @@ static int build_stages(const smrt_vae* h, const FusedArgs& f, FusedStage* stage
         t.kind = (l == L + 1) ? FK_BWD_LATENT : FK_BWD_ACT;
         std::swap(cur, nxt);
     }
+    for (int i = 0; i < ns; ++i) stages[i].variant = stage_variant(stages[i].kind, stages[i].K16, stages[i].act);
     return ns;
 }
 
@@ -559,7 +581,7 @@ static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_r
     hipStream_t s = h->stream;
     const FusedArgs& f = h->fplan;
     PersistArgs a{};
-    a.n_stages = build_stages(h, f, a.stages);
+    a.n_stages = h->n_stage_u; a.stage_u = h->stage_u;
     const int n_owner = persist_owner_workgroups(h->tiles16);
     a.G = G;
     a.NL = h->NL; a.L = h->L; a.Z = h->Z; a.D = h->D;
@@ -582,17 +604,22 @@ static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_r
     if (inject_fault && hipMemsetAsync(h->pcnt + 192, 1, sizeof(unsigned), s) != hipSuccess) return -1;
 #ifdef SMRT_STAMPS
     static unsigned long long* pdbg = nullptr;
-    if (!pdbg) { (void)hipMalloc((void**)&pdbg, 64 * 8); (void)hipMemset(pdbg, 0, 64 * 8); }
+    if (!pdbg) { (void)hipMalloc((void**)&pdbg, 160 * 8); (void)hipMemset(pdbg, 0, 160 * 8); }
     a.dbg = pdbg;
 #endif
     { ProfScope ps(h, PK_PERSIST); launch_persist_train(s, a, G + n_owner); }
 #ifdef SMRT_STAMPS
     {
         (void)hipStreamSynchronize(s);
-        unsigned long long hb[64];
-        (void)hipMemcpy(hb, pdbg, 64 * 8, hipMemcpyDeviceToHost);
+        unsigned long long hb[160];
+        (void)hipMemcpy(hb, pdbg, 160 * 8, hipMemcpyDeviceToHost);
         static int once = 0;
         if (once++ == 2) {
+            for (int st = 0; st < 12 && hb[64 + 8 * st]; ++st) {
+                const unsigned long long* t = hb + 64 + 8 * st;
+                fprintf(stderr, "stage %d wave 0, shader cycles: decode + addresses %lld | fragment addresses %lld | reads + MFMAs + sums %lld | epilogue %lld | barrier %lld\n",
+                        st, (long long)(t[0] - (st ? t[-4] : t[0])), (long long)(t[1] - t[0]), (long long)(t[2] - t[1]), (long long)(t[3] - t[2]), (long long)(t[4] - t[3]));
+            }
             const char* nm[64] = {nullptr};
             nm[1] = "weights published (poll)"; nm[2] = "image -> LDS"; nm[3] = "x tile, barrier";
             nm[40] = "stages done"; nm[41] = "stores drained + barrier";

@@ -129,6 +129,9 @@ __global__ __launch_bounds__(FTHREADS) void fused_fwd_bwd_kernel(const FusedArgs
 
     // ---- every GEMM stage (forward layers, then backward through the activations) runs through this one body
     StageCtx sx;
+#ifdef SMRT_STAMPS
+    sx.sdbg = nullptr;
+#endif
     sx.lds = lds; sx.wave = wave; sx.c = c; sx.q = q; sx.tid = tid; sx.rows_here = rows_here; sx.Z = Z; sx.s_z = s_z;
     sx.lo = lo; sx.hi = hi; sx.inv_batch = inv_batch; sx.es = es; sx.zs = zs; sx.Zb_g = a.Zb_g; sx.blk = blockIdx.x;
     int4 d0 = sdesc[0], d1 = sdesc[1], d2 = sdesc[2], d3 = sdesc[3], d4 = sdesc[4];

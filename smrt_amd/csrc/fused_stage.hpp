@@ -4,6 +4,8 @@
 #include "vae_kernels.hpp"
 #include "device_utils.hpp"
 
+#include <type_traits>
+
 namespace smrt {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -100,152 +102,266 @@ struct StageCtx {
     float* zs;                // z tile in LDS
     float* Zb_g;              // TO_GLOBAL only: z, blocked transposed
     long blk;                 // TO_GLOBAL only: this workgroup's 16-row block inside the global activation buffers
+#ifdef SMRT_STAMPS
+    unsigned long long* sdbg; // diagnostic builds: 4 shader-clock stamps per stage (entry, addresses ready, sums ready, stored)
+#endif
+};
+#ifdef SMRT_STAMPS
+#define XST(i) do { if (x.sdbg && x.tid == 0) x.sdbg[i] = clock64(); } while (0)
+#else
+#define XST(i) do { } while (0)
+#endif
+
+// ONE GEMM stage (forward through a layer, or backward through it) of a 16-row tile runs in two parts:
+//   decode: the stage's record -> StageDec: the uniform scalars and this lane's addresses for the wave's first 16-column
+//           block.  decode_stage reads the 80-byte FusedStage from registers (the per-launch kernel: ~170 instructions);
+//           decode_stage_u takes the host-decoded StageU that one scalar load left in SGPRs (the persistent kernel, which
+//           runs the same stages thousands of times per launch: ~25 instructions);
+//   exec_stage: fragments -> MFMAs -> fused epilogue, for the wave's column blocks n0 = 16 wave, + 128, ...
+// TO_GLOBAL (1 plain, 2 write-through stores, 0 nothing): also stream the stage's output to the blocked-transposed global
+// buffer (the weight-gradient side reads it).  The caller runs lds_barrier() after exec_stage, then (after a FK_FWD_HEADS
+// stage) reparam_after_heads().
+struct StageDec {
+    int nb_all, nn, N, N16, kind, act, trans, s_out, s_aux, bstep, bstride, Zq;     // (uniform)
+    int out_off, wrote_tail;                                                        // (uniform) FK_BWD_LATENT: tail to clear
+    const float* ap;          // this lane's A fragment base (activations)
+    const float* bp;          // this lane's weight fragment base, first column block
+    float* o;                 // this lane's output element (row 4 q, column n) in the LDS tile, first column block
+    gfloat* g;                // the same in the global blocked-transposed buffer
+    const float* po;          // auxiliary tile element (x / producing layer's output), first column block
+    const float* pb;          // bias image element, first column block
+    int n;                    // this lane's column in the first block
 };
 
-// ONE GEMM stage (forward through a layer, or backward through it) of a 16-row tile, from its 80-byte record d0..d4
-// (FusedStage).  TO_GLOBAL (1 plain, 2 write-through stores, 0 nothing): also stream the stage's output to the blocked-transposed global buffer (the two-kernel step's
-// weight-gradient kernel reads it); the persistent kernel keeps everything in LDS.  Returns the stage kind.
-// The caller runs lds_barrier() after it, then (after a FK_FWD_HEADS stage) reparam_after_heads().
-template <int TO_GLOBAL>
-__device__ __forceinline__ int run_stage(const int4 d0, const int4 d1, const int4 d2, const int4 d3, const int4 d4,
-                                         const StageCtx& x, float& bce) {
+// SK / SNB / SACT: the stage's kind, its number of 16-wide k-blocks and its activation when they are known at compile time
+// (-1 / 0 / -1: read from the record).  With them the body is straight-line code: no dispatch on the kind, no chunk ladder,
+// no activation switch.
+template <int SK = -1, int SNB = 0, int SACT = -1>
+__device__ __forceinline__ StageDec decode_stage(const int4 d0, const int4 d1, const int4 d2, const int4 d3, const int4 d4,
+                                                 const StageCtx& x) {
     float* const lds = x.lds;
-    const int wave = x.wave, c = x.c, q = x.q, tid = x.tid, rows_here = x.rows_here, Z = x.Z, s_z = x.s_z;
+    const int wave = x.wave, c = x.c, q = x.q;
+    const int in_off = UNI(d0.x), sin = UNI(d0.y), K16 = SNB > 0 ? 16 * SNB : UNI(d0.z), w_off = UNI(d0.w);
+    const int nn = UNI(d1.x), N = UNI(d1.y), kind = SK >= 0 ? SK : UNI(d1.z), act = SACT >= 0 ? SACT : UNI(d1.w);
+    const int out_off = UNI(d2.x), s_out = UNI(d2.y), b_off = UNI(d2.z), aux_off = UNI(d2.w);
+    const int s_aux = UNI(d3.x), NF = UNI(d3.y), trans = SK >= 0 ? (SK >= FK_BWD_ACT ? 1 : 0) : UNI(d3.z);
+    gfloat* gblk = (gfloat*)(((unsigned long long)(unsigned)UNI(d4.y) << 32) | (unsigned)UNI(d4.x)) + x.blk * NF * 16;
+    StageDec s;
+    s.nb_all = K16 >> 4; s.nn = nn; s.N = N; s.N16 = (N + 15) & ~15; s.kind = kind; s.act = act; s.trans = trans;
+    s.s_out = s_out; s.s_aux = s_aux; s.out_off = out_off;
+    s.bstep = trans ? 64 : (nn << 4);                                     // floats per 16 k
+    s.bstride = trans ? 128 * nn : 512;                                   // floats per 128 columns (the next column block of a wave)
+    const int n = wave * 16 + c;
+    s.n = n;
+    s.ap = lds + in_off + c * sin + 4 * q;
+    s.bp = trans ? lds + w_off + ((((n >> 2) * nn) + 4 * q) << 2) + (n & 3)     // Wop[k][n] = W[kf = n][nf = k]
+                 : lds + w_off + ((q * nn + n) << 2);                          // Wop[k][n] = W[kf = k][nf = n]
+    s.o = lds + out_off + (4 * q) * s_out + n;
+    s.g = gblk + n * 16 + 4 * q;
+    s.po = lds + aux_off + (4 * q) * s_aux + n;
+    s.pb = lds + b_off + 4 * n;
+    s.Zq = (4 * q) * x.s_z;
+    s.wrote_tail = 0;
+    return s;
+}
+
+template <int TO_GLOBAL, int SK = -1, int SNB = 0, int SACT = -1>
+__device__ __forceinline__ int exec_stage(const StageDec& s, const StageCtx& x, float& bce) {
+    float* const lds = x.lds;
+    const int wave = x.wave, q = x.q, tid = x.tid, rows_here = x.rows_here, Z = x.Z, s_z = x.s_z;
     const float lo = x.lo, hi = x.hi, inv_batch = x.inv_batch;
     const float* const es = x.es;
-        const int in_off = UNI(d0.x), sin = UNI(d0.y), K16 = UNI(d0.z), w_off = UNI(d0.w);
-        const int nn = UNI(d1.x), N = UNI(d1.y), kind = UNI(d1.z), act = UNI(d1.w);
-        const int out_off = UNI(d2.x), s_out = UNI(d2.y), b_off = UNI(d2.z), aux_off = UNI(d2.w);
-        const int s_aux = UNI(d3.x), NF = UNI(d3.y), trans = UNI(d3.z);
-        gfloat* gblk = (gfloat*)(((unsigned long long)(unsigned)UNI(d4.y) << 32) | (unsigned)UNI(d4.x))
-                       + x.blk * NF * 16;
-        const int N16 = (N + 15) & ~15;
-        const float* ap = lds + in_off + c * sin + 4 * q;
-
+    const int kind = SK >= 0 ? SK : s.kind, act = SACT >= 0 ? SACT : s.act;
+    const int trans = SK >= 0 ? (SK >= FK_BWD_ACT ? 1 : 0) : s.trans;
+    const int N = s.N, N16 = s.N16, s_out = s.s_out, s_aux = s.s_aux, bstep = s.bstep;
+    XST(0);
+    int n = s.n;
+    const float* bp0 = s.bp;
+    float* o = s.o;
+    gfloat* g = s.g;
+    const float* po = s.po;
+    const float* pbias = s.pb;
+    auto block = [&]() {        // one 16-column block of this wave
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        // k runs in chunks of NB 16-wide k-blocks, NB a compile-time 8 / 4 / 2 / 1: a chunk is straight-line code -- ALL its
+        // fragments are requested first, then its 4 NB MFMAs run into 4 independent chains while the later reads are
+        // still landing (the compiler counts lgkmcnt down block by block; with run-time guards around the blocks it
+        // waited for every read before the first MFMA and copied the fragment registers around the guards).  Nets on
+        // this path have K in {16, 32, 64, 128} almost always, i.e. exactly one chunk per stage.
+        const float* apc = s.ap;
+        const float* bp = bp0;
+        int left = s.nb_all;
+        XST(1);
+        if constexpr (SNB > 0 && SK >= 0) {            // the whole k extent as ONE straight-line chunk
+            k_chunk<SNB, (SK >= FK_BWD_ACT)>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+            left = 0;
+        }
 #pragma unroll 1
-        for (int n0 = wave * 16; n0 < N16; n0 += 16 * FWAVES) {
-            const int n = n0 + c;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-            // k runs in chunks of NB 16-wide k-blocks, NB a compile-time 8 / 4 / 2 / 1: a chunk is straight-line code -- ALL its
-            // fragments are requested first, then its 4 NB MFMAs run into 4 independent chains while the later reads are
-            // still landing (the compiler counts lgkmcnt down block by block; with run-time guards around the blocks it
-            // waited for every read before the first MFMA and copied the fragment registers around the guards).  Nets on
-            // this path have K in {16, 32, 64, 128} almost always, i.e. exactly one chunk per stage.
-            const int nb_all = K16 >> 4;
-            const float* apc = ap;
-            const float* bp = trans ? lds + w_off + ((((n >> 2) * nn) + 4 * q) << 2) + (n & 3)     // Wop[k][n] = W[kf = n][nf = k]
-                                    : lds + w_off + ((q * nn + n) << 2);                          // Wop[k][n] = W[kf = k][nf = n]
-            const int bstep = trans ? 64 : (nn << 4);                                             // floats per 16 k
-            int left = nb_all;
-#pragma unroll 1
-            for (; left >= 8; left -= 8) {
-                if (trans) k_chunk<8, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                else       k_chunk<8, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                apc += 128; bp += 8 * bstep;
-            }
-            if (left & 4) {
-                if (trans) k_chunk<4, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                else       k_chunk<4, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                apc += 64; bp += 4 * bstep;
-            }
-            if (left & 2) {
-                if (trans) k_chunk<2, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                else       k_chunk<2, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                apc += 32; bp += 2 * bstep;
-            }
-            if (left & 1) {
-                if (trans) k_chunk<1, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-                else       k_chunk<1, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
-            }
-            float v[4];
+        for (; left >= 8; left -= 8) {
+            if (trans) k_chunk<8, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+            else       k_chunk<8, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+            apc += 128; bp += 8 * bstep;
+        }
+        if (left & 4) {
+            if (trans) k_chunk<4, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+            else       k_chunk<4, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+            apc += 64; bp += 4 * bstep;
+        }
+        if (left & 2) {
+            if (trans) k_chunk<2, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+            else       k_chunk<2, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+            apc += 32; bp += 2 * bstep;
+        }
+        if (left & 1) {
+            if (trans) k_chunk<1, true>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+            else       k_chunk<1, false>(apc, bp, bstep, acc0, acc1, acc2, acc3);
+        }
+        float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
-            // rows 4q .. 4q+3 of column n.  Workspace rows are padded to a multiple of 16, so rows past the batch are
-            // computed and stored like the others (their dPre is forced to 0, nothing reads them).
-            float* o = lds + out_off + (4 * q) * s_out + n;
-            gfloat* g = gblk + n * 16 + 4 * q;
-            if (kind <= FK_FWD_HEADS) {
-                // y = act(x.W + b)                                                     layer.py:368
-                if (n < N) {
-                    const float bcol = lds[b_off + 4 * n];
+        for (int r = 0; r < 4; ++r) v[r] = (acc0[r] + acc1[r]) + (acc2[r] + acc3[r]);
+#ifdef SMRT_STAMPS
+        if (x.sdbg && x.tid == 0) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); x.sdbg[2] = clock64(); }
+#endif
+        // rows 4q .. 4q+3 of column n.  Workspace rows are padded to a multiple of 16, so rows past the batch are
+        // computed and stored like the others (their dPre is forced to 0, nothing reads them).
+        if (kind <= FK_FWD_HEADS) {
+            // y = act(x.W + b)                                                     layer.py:368
+            if (n < N) {
+                const float bcol = *pbias;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += bcol;
-                    act_fwd4(act, v);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r * s_out] = v[r];
-                    stage_store<TO_GLOBAL>(g, f32x4{v[0], v[1], v[2], v[3]});
-                }
-            } else if (kind == FK_FWD_BCE) {
-                // sigmoid output + clipped Bernoulli NLL + dL/dpre (layer.py:333-338, _ae_utils.py:31-32)
-                if (n < N) {
-                    const float bcol = lds[b_off + 4 * n];
-                    const float* xr = lds + aux_off + (4 * q) * s_aux + n;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool valid = (4 * q + r) < rows_here;
-                        const float p = fast_sigmoid(v[r] + bcol);
-                        const float x = xr[r * s_aux];
-                        const float pl = tf_maximum(p, lo), pc = tf_minimum(pl, hi), om = 1.0f - pc;
-                        const float term = x * __logf(pc) + (1.0f - x) * __logf(om);
-                        bce -= valid ? term : 0.0f;
-                        // TF clip_by_value gradient gate: Maximum passes where p >= lo, Minimum where max(p,lo) <= hi
-                        const bool pass = valid && (p >= lo) && (pl <= hi);
-                        const float dp = pass ? -(x * __builtin_amdgcn_rcpf(pc) - (1.0f - x) * __builtin_amdgcn_rcpf(om)) * inv_batch : 0.0f;
-                        v[r] = valid ? dp * p * (1.0f - p) : 0.0f;
-                        o[r * s_out] = v[r];
-                    }
-                    stage_store<TO_GLOBAL>(g, f32x4{v[0], v[1], v[2], v[3]});
-                }
-            } else if (kind == FK_BWD_ACT) {
-                // dPre_prev = (dPre . W^T) * act'(y_prev); pad columns come out as exact zeros (zero weights, zero y)
-                const float* po = lds + aux_off + (4 * q) * s_aux + n;
-                float yv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) yv[r] = po[r * s_aux];
-                act_bwd4(act, yv, v);
+                for (int r = 0; r < 4; ++r) v[r] += bcol;
+                act_fwd4(act, v);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r * s_out] = v[r];
                 stage_store<TO_GLOBAL>(g, f32x4{v[0], v[1], v[2], v[3]});
-            } else {
-                // FK_BWD_LATENT: v = dL/dz through the reparameterisation and the KL term into both heads
-                //   dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B     layer.py:279, _ae_utils.py:49
-                if (n < N) {
-                    const float* po = lds + aux_off + (4 * q) * s_aux + n;
-                    const float* er = es + (4 * q) * s_z + n;
-                    float mu[4], ls[4], g_mu[4], g_ls[4];
+            }
+        } else if (kind == FK_FWD_BCE) {
+            // sigmoid output + clipped Bernoulli NLL + dL/dpre (layer.py:333-338, _ae_utils.py:31-32)
+            if (n < N) {
+                const float bcol = *pbias;
+                const float* xr = po;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        mu[r] = po[r * s_aux];
-                        ls[r] = po[r * s_aux + Z];
-                        const float e = er[r * s_z];
-                        const float el = __expf(ls[r]);
-                        g_mu[r] = v[r] + mu[r] * inv_batch;
-                        g_ls[r] = v[r] * e * el + (el * el - 1.0f) * inv_batch;
-                    }
-                    act_bwd4(act, mu, g_mu);
-                    act_bwd4(act, ls, g_ls);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool valid = (4 * q + r) < rows_here;
-                        g_mu[r] = valid ? g_mu[r] : 0.0f;
-                        g_ls[r] = valid ? g_ls[r] : 0.0f;
-                        o[r * s_out] = g_mu[r];
-                        o[r * s_out + Z] = g_ls[r];
-                    }
-                    stage_store<TO_GLOBAL>(g, f32x4{g_mu[0], g_mu[1], g_mu[2], g_mu[3]});
-                    stage_store<TO_GLOBAL>(g + Z * 16, f32x4{g_ls[0], g_ls[1], g_ls[2], g_ls[3]});
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = (4 * q + r) < rows_here;
+                    const float p = fast_sigmoid(v[r] + bcol);
+                    const float xx = xr[r * s_aux];
+                    const float pl = tf_maximum(p, lo), pc = tf_minimum(pl, hi), om = 1.0f - pc;
+                    const float term = xx * __logf(pc) + (1.0f - xx) * __logf(om);
+                    bce -= valid ? term : 0.0f;
+                    // TF clip_by_value gradient gate: Maximum passes where p >= lo, Minimum where max(p,lo) <= hi
+                    const bool pass = valid && (p >= lo) && (pl <= hi);
+                    const float dp = pass ? -(xx * __builtin_amdgcn_rcpf(pc) - (1.0f - xx) * __builtin_amdgcn_rcpf(om)) * inv_batch : 0.0f;
+                    v[r] = valid ? dp * p * (1.0f - p) : 0.0f;
+                    o[r * s_out] = v[r];
                 }
+                stage_store<TO_GLOBAL>(g, f32x4{v[0], v[1], v[2], v[3]});
+            }
+        } else if (kind == FK_BWD_ACT) {
+            // dPre_prev = (dPre . W^T) * act'(y_prev); pad columns come out as exact zeros (zero weights, zero y)
+            float yv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yv[r] = po[r * s_aux];
+            act_bwd4(act, yv, v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r * s_out] = v[r];
+            stage_store<TO_GLOBAL>(g, f32x4{v[0], v[1], v[2], v[3]});
+        } else {
+            // FK_BWD_LATENT: v = dL/dz through the reparameterisation and the KL term into both heads
+            //   dmu = dz + mu/B ; dls = dz*eps*exp(ls) + (exp(2 ls) - 1)/B     layer.py:279, _ae_utils.py:49
+            if (n < N) {
+                const float* er = es + s.Zq + n;
+                float mu[4], ls[4], g_mu[4], g_ls[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mu[r] = po[r * s_aux];
+                    ls[r] = po[r * s_aux + Z];
+                    const float e = er[r * s_z];
+                    const float el = __expf(ls[r]);
+                    g_mu[r] = v[r] + mu[r] * inv_batch;
+                    g_ls[r] = v[r] * e * el + (el * el - 1.0f) * inv_batch;
+                }
+                act_bwd4(act, mu, g_mu);
+                act_bwd4(act, ls, g_ls);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = (4 * q + r) < rows_here;
+                    g_mu[r] = valid ? g_mu[r] : 0.0f;
+                    g_ls[r] = valid ? g_ls[r] : 0.0f;
+                    o[r * s_out] = g_mu[r];
+                    o[r * s_out + Z] = g_ls[r];
+                }
+                stage_store<TO_GLOBAL>(g, f32x4{g_mu[0], g_mu[1], g_mu[2], g_mu[3]});
+                stage_store<TO_GLOBAL>(g + Z * 16, f32x4{g_ls[0], g_ls[1], g_ls[2], g_ls[3]});
             }
         }
-        if (kind == FK_BWD_LATENT) {
-            // the next stage reads k up to rup16(2Z): clear the tail this stage did not write
-            const int wrote = 2 * Z, tail = ((wrote + 15) & ~15) - wrote;
-            for (int i = tid; i < FTM * tail; i += FTHREADS) {
-                const int r = i / tail;
-                lds[out_off + r * s_out + wrote + (i - r * tail)] = 0.f;
-            }
+    };
+#pragma unroll 1
+    for (int n0 = wave * 16; n0 < N16; n0 += 16 * FWAVES) {
+        block();
+        n += 16 * FWAVES; bp0 += s.bstride; o += 16 * FWAVES; g += 16 * FWAVES * 16; po += 16 * FWAVES; pbias += 4 * 16 * FWAVES;
+    }
+    XST(3);
+    if (kind == FK_BWD_LATENT) {
+        // the next stage reads k up to rup16(2Z): clear the tail this stage did not write
+        const int wrote = 2 * Z, tail = ((wrote + 15) & ~15) - wrote;
+        for (int i = tid; i < FTM * tail; i += FTHREADS) {
+            const int r = i / tail;
+            lds[s.out_off + r * s_out + wrote + (i - r * tail)] = 0.f;
         }
-        return kind;
+    }
+    return kind;
+}
+
+// decode + execute in one call (the per-launch two-kernel step)
+template <int TO_GLOBAL>
+__device__ __forceinline__ int run_stage(const int4 d0, const int4 d1, const int4 d2, const int4 d3, const int4 d4,
+                                         const StageCtx& x, float& bce) {
+    const StageDec s = decode_stage<>(d0, d1, d2, d3, d4, x);
+    return exec_stage<TO_GLOBAL>(s, x, bce);
+}
+
+static_assert(STAGE_ACT_SIGMOID == ACT_SIGMOID, "stage_variant's activation id");
+// The host-decoded record, as one scalar load left it in SGPRs -> StageDec.  24-bit multiplies: every factor is an LDS
+// offset or a lane index.
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ StageDec decode_stage_u(const i32x16 u, const StageCtx& x) {
+    float* const lds = x.lds;
+    const int c = x.c, q = x.q, n = x.wave * 16 + c;
+    StageDec s;
+    const int nn = u[4], packed = u[6];
+    const int trans = (packed >> 16) & 255;
+    s.nb_all = u[2]; s.nn = nn; s.N = u[5]; s.N16 = u[7]; s.kind = packed & 255; s.act = (packed >> 8) & 255; s.trans = trans;
+    s.s_out = u[9]; s.s_aux = u[12]; s.out_off = u[8];
+    s.bstep = trans ? 64 : (nn << 4);
+    s.bstride = trans ? 128 * nn : 512;
+    s.n = n;
+    s.ap = lds + (__mul24(c, u[1]) + 4 * q + u[0]);
+    s.bp = trans ? lds + (((__mul24(n >> 2, nn) + 4 * q) << 2) + (n & 3) + u[3])
+                 : lds + (((__mul24(q, nn) + n) << 2) + u[3]);
+    s.o = lds + (__mul24(4 * q, u[9]) + n + u[8]);
+    s.po = lds + (__mul24(4 * q, u[12]) + n + u[11]);
+    s.pb = lds + (4 * n + u[10]);
+    gfloat* gout = (gfloat*)(((unsigned long long)(unsigned)u[15] << 32) | (unsigned)u[14]);
+    s.g = gout + (x.blk * u[13] + (n * 16 + 4 * q));
+    s.Zq = (4 * q) * x.s_z;
+    s.wrote_tail = 0;
+    return s;
+}
+
+// exec_stage through the variant the record names (vae_kernels.hpp: stage_variant): the structure-specialised copy of the
+// body when there is one, else the generic body.  The switch is wave-uniform (one scalar jump).
+template <int TO_GLOBAL>
+__device__ __forceinline__ int exec_stage_variant(int variant, const StageDec& cur, const StageCtx& x, float& bce) {
+    switch (variant) {
+#define SMRT_SV1(K_, NB_) \
+        case stage_variant(K_, 16 * NB_, ACT_SIGMOID): return exec_stage<TO_GLOBAL, K_, NB_, ACT_SIGMOID>(cur, x, bce); \
+        case stage_variant(K_, 16 * NB_, -1):          return exec_stage<TO_GLOBAL, K_, NB_, -1>(cur, x, bce);
+#define SMRT_SV(K_) SMRT_SV1(K_, 1) SMRT_SV1(K_, 2) SMRT_SV1(K_, 4) SMRT_SV1(K_, 8)
+        SMRT_SV(FK_FWD_ACT) SMRT_SV(FK_FWD_HEADS) SMRT_SV(FK_FWD_BCE) SMRT_SV(FK_BWD_ACT) SMRT_SV(FK_BWD_LATENT)
+#undef SMRT_SV
+#undef SMRT_SV1
+        default: return exec_stage<TO_GLOBAL>(cur, x, bce);
+    }
 }
 
 // z = mu + eps * exp(log_sigma) and the KL row terms, after the heads stage's barrier; ends with its own barrier.

@@ -224,7 +224,6 @@ __device__ __forceinline__ void owner_role(const PersistArgs& a, int* go_flag, f
 __global__ __launch_bounds__(FTHREADS) void persist_train_kernel(const PersistArgs a) {
     extern __shared__ __align__(16) float lds[];
     __shared__ float red[FWAVES], red2[FWAVES];
-    __shared__ int4 sdesc[2 * MAX_LAYERS * 5 + 5];
     __shared__ int go_flag;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = UNI(tid >> 6);
@@ -242,11 +241,10 @@ __global__ __launch_bounds__(FTHREADS) void persist_train_kernel(const PersistAr
     const int n_owner = (int)gridDim.x - G;
     const __amdgpu_buffer_rsrc_t r_img = make_rsrc(a.Wimg, (unsigned)(a.img_total * 4));
 
-    // ---- launch prologue: stage records, zeroed activation tiles
+    // ---- launch prologue: zeroed activation tiles
+    typedef const __attribute__((address_space(4))) i32x16 stage_rec_t;      // constant address space: uniform index -> s_load_dwordx16
+    stage_rec_t* const stage_tab = (stage_rec_t*)(unsigned long long)a.stage_u;
     {
-        const int nw = a.n_stages * 5;
-        const int4* src = reinterpret_cast<const int4*>(&a.stages[0]);
-        if (tid < nw) sdesc[tid] = src[tid];
         float4* l4 = reinterpret_cast<float4*>(lds);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = (a.img_total >> 2) + tid; i < a.lds_total / 4; i += FTHREADS) l4[i] = z4;
@@ -351,16 +349,27 @@ __global__ __launch_bounds__(FTHREADS) void persist_train_kernel(const PersistAr
             StageCtx sx;
             sx.lds = lds; sx.wave = wave; sx.c = c; sx.q = q; sx.tid = tid; sx.rows_here = rows_here; sx.Z = Z; sx.s_z = s_z;
             sx.lo = lo; sx.hi = hi; sx.inv_batch = inv_batch; sx.es = es; sx.zs = zs; sx.Zb_g = a.Zb_g; sx.blk = wg;
-            int4 d0 = sdesc[0], d1 = sdesc[1], d2 = sdesc[2], d3 = sdesc[3], d4 = sdesc[4];
+            // the stage records come decoded from the host, one scalar load each; the next stage's is requested in front of
+            // this stage's barrier (behind its last LDS access: a scalar load in flight would turn the fragment reads'
+            // counted waits into waits for everything)
+            i32x16 u = stage_tab[0];
 #pragma unroll 1
             for (int st = 0; st < a.n_stages; ++st) {
-                const int4 e0 = sdesc[5 * st + 5], e1 = sdesc[5 * st + 6], e2 = sdesc[5 * st + 7], e3 = sdesc[5 * st + 8],
-                           e4 = sdesc[5 * st + 9];
-                const int kind = run_stage<2>(d0, d1, d2, d3, d4, sx, bce);
+#ifdef SMRT_STAMPS
+                sx.sdbg = (a.dbg && wg == 0 && step == 4) ? a.dbg + 64 + 8 * st : nullptr;
+#endif
+                const StageDec cur = decode_stage_u(u, sx);
+                const int out_off = u[8], s_out = u[9];
+                const int kind = exec_stage_variant<2>((u[6] >> 24) & 255, cur, sx, bce);
+                __builtin_amdgcn_sched_barrier(0);
+                u = stage_tab[st + 1];
+                __builtin_amdgcn_sched_barrier(0);
                 lds_barrier();
-                if (kind == FK_FWD_HEADS) reparam_after_heads<2>(d2, sx, kl);
+#ifdef SMRT_STAMPS
+                if (sx.sdbg && tid == 0) sx.sdbg[4] = clock64();
+#endif
+                if (kind == FK_FWD_HEADS) reparam_after_heads<2>(make_int4(out_off, s_out, 0, 0), sx, kl);
                 PST(4 + st);
-                d0 = e0; d1 = e1; d2 = e2; d3 = e3; d4 = e4;
             }
         }
         PST(40);

@@ -285,14 +285,32 @@ struct FusedLayer {       // host-side LDS plan of one dense layer
 // One GEMM stage of the kernel (forward through a layer, or backward through it): ONE code path runs every
 // stage from this 80-byte record, so the instruction footprint of the kernel is one stage, not 2L+3 of them.
 enum FusedKind : int { FK_FWD_ACT = 0, FK_FWD_HEADS = 1, FK_FWD_BCE = 2, FK_BWD_ACT = 3, FK_BWD_LATENT = 4 };
+// Stage bodies whose STRUCTURE is fixed at compile time (fused_stage.hpp: run_stage_variant): the stage kind, its k extent
+// as 1 / 2 / 4 / 8 16-wide k-blocks and whether the activation is the sigmoid.  0 = the generic body.
+constexpr int STAGE_ACT_SIGMOID = 3;           // == ACT_SIGMOID (device_utils.hpp) == SMRT_ACT_SIGMOID (smrt_hip.h)
+constexpr int stage_variant(int kind, int k16, int act) {
+    const int nb = k16 >> 4;
+    const int ix = (k16 & 15) ? -1 : (nb == 1 ? 0 : (nb == 2 ? 1 : (nb == 4 ? 2 : (nb == 8 ? 3 : -1))));
+    return ix < 0 ? 0 : 1 + ((kind * 4 + ix) << 1) + (act == STAGE_ACT_SIGMOID ? 1 : 0);
+}
 struct FusedStage {
     int in_off, sin, K16, w_off;      // A operand tile (LDS offset, row stride), padded k extent, weight image offset
     int nn, N, kind, act;             // image column count, valid output columns, FusedKind, activation id
     int out_off, s_out, b_off, aux_off;   // LDS tile written by the epilogue; bias image; auxiliary tile (x / producing layer's output)
-    int s_aux, NF, trans, pad;        // aux row stride; feature count of the global buffer; 1: sum over fan-out (backward)
+    int s_aux, NF, trans, variant;    // aux row stride; feature count of the global buffer; 1: sum over fan-out (backward); stage_variant()
     float* gout; long pad2;           // global [row block][NF][16] buffer the epilogue streams to
 };
 static_assert(sizeof(FusedStage) == 80, "FusedStage is read as five 16-byte LDS words");
+// The same stage, decoded on the host for the persistent kernel: 16 words in device memory that ONE scalar load brings into
+// SGPRs (the kernel runs the same stages thousands of times per launch; decoding the 80-byte record per stage and step was a
+// third of the instructions its compute waves issued).
+struct StageU {
+    int in_off, sin, nb_all, w_off;       // A tile (LDS offset, row stride), 16-wide k-blocks, weight image offset
+    int nn, N, packed, N16;               // image column count, valid / padded output columns, kind | act << 8 | trans << 16 | variant << 24
+    int out_off, s_out, b_off, aux_off;
+    int s_aux, NF16, gout_lo, gout_hi;    // aux row stride; floats per 16-row block of the global buffer; its address
+};
+static_assert(sizeof(StageU) == 64, "StageU is read by one s_load_dwordx16");
 struct FusedArgs {
     FusedStage stages[2 * MAX_LAYERS];
     int n_stages;
@@ -344,7 +362,7 @@ struct DwSlabArgs {            // weight-gradient tiles of a row range into grad
 void launch_fused_dw_slab(hipStream_t s, const DwSlabArgs& a, int splits);
 // Persistent whole-epoch training kernel (persist_train.hip)
 struct PersistArgs {
-    FusedStage stages[2 * MAX_LAYERS];    // the same records as the per-launch kernel
+    const StageU* stage_u;                // n_stages + 1 decoded records (the last one a copy: read ahead, never run), 64-byte aligned
     int n_stages;
     int G;                                // compute workgroups (blockIdx < G); the rest of the grid are owner workgroups
     int NL, L, Z, D;
