@@ -131,6 +131,12 @@ int  smrt_vae_train_epochs_multi(smrt_vae** hs, int32_t n_handles, const float* 
 int32_t smrt_persistent_budget(int32_t device);
 int32_t smrt_vae_persistent_workgroups(const smrt_vae* h, int32_t batch_rows);
 int  smrt_vae_set_persistent(smrt_vae* h, int32_t mode);
+/* Which build of the persistent kernel h's launches use (known once its training workspace exists; 0 before, and for nets
+ * off this path): 1 -- the generic one, a loop over the net's stage records; 2 -- one written out for the net's shape (a VAE with one
+ * hidden layer and sigmoid activations whose padded widths are 16 / 32 / 64 / 128 features, 32 / 64 / 128 hidden, <= 32 latent:
+ * no loop, each stage its structure-specialised body).  Both run the same arithmetic in the same order: results are
+ * bit-identical (tests/test_gpu_parity.py).  SMRT_HIP_PERSIST_SEQ=0 keeps every net on the generic one. */
+int32_t smrt_vae_persistent_form(const smrt_vae* h);
 
 /* Data-parallel halves of a step (no reference counterpart): grad_step leaves
  * [internal-layout gradient sums | sum of row losses] scaled by 1/global_rows in grads_dev

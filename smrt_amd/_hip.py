@@ -24,7 +24,7 @@ EXPORTS = [
     "smrt_vae_create", "smrt_vae_destroy", "smrt_vae_param_count", "smrt_vae_set_params",
     "smrt_vae_get_params", "smrt_vae_get_opt_state", "smrt_vae_reset_opt_state", "smrt_vae_step_count",
     "smrt_vae_set_dropout_masks", "smrt_vae_train_step", "smrt_vae_train_epochs", "smrt_vae_train_epochs_multi",
-    "smrt_vae_dp_count", "smrt_persistent_budget", "smrt_vae_persistent_workgroups", "smrt_vae_set_persistent",
+    "smrt_vae_dp_count", "smrt_persistent_budget", "smrt_vae_persistent_workgroups", "smrt_vae_set_persistent", "smrt_vae_persistent_form",
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_generate_noalloc", "smrt_vae_generate_noalloc_max_rows", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
@@ -93,6 +93,7 @@ def load():
                                                 f32p, f32p]
     lib.smrt_persistent_budget.argtypes = [i32]; lib.smrt_persistent_budget.restype = i32
     lib.smrt_vae_persistent_workgroups.argtypes = [vp, i32]; lib.smrt_vae_persistent_workgroups.restype = i32
+    lib.smrt_vae_persistent_form.argtypes = [vp]; lib.smrt_vae_persistent_form.restype = i32
     lib.smrt_vae_set_persistent.argtypes = [vp, i32]
     lib.smrt_vae_grad_step.argtypes = [vp, vp, i64, i32, i64, i64, vp, vp]
     lib.smrt_vae_apply_grads.argtypes = [vp, vp, f32p]
@@ -550,6 +551,11 @@ class VaeHandle(object):
     def persistent_workgroups(self, batch_rows):
         """Workgroups one persistent whole-epoch launch of this handle holds (0: the net or the schedule does not qualify)."""
         return int(self._lib.smrt_vae_persistent_workgroups(self._live(), int(batch_rows)))
+
+    @property
+    def persistent_form(self):
+        """0: not (yet) on the persistent path; 1: the generic persistent kernel; 2: one written out for this net's shape."""
+        return int(self._lib.smrt_vae_persistent_form(self._live()))
 
     def set_persistent(self, mode):
         """-1: persistent path when the device's budget has room at call time; 0: never; 1: always (budget planned by the caller)."""

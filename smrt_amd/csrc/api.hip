@@ -108,6 +108,7 @@ struct smrt_vae {
     DwTile* tile_tab = nullptr;      // per-tile records of the fused dW + optimizer kernel
     StageU* stage_u = nullptr;       // the persistent kernel's stage records, decoded (ensure_train)
     int n_stage_u = 0;
+    persist_kernel_t pkernel = nullptr;   // the persistent kernel for this net: a sequence-specialised instantiation or the generic one
     DwRec* dwrec = nullptr;          // small-batch fused weight-gradient + update launch: 32x32 tile records, then 64x64 ones
     int n_rec32 = 0, n_rec64 = 0;
     // persistent whole-epoch kernel (persist_train.hip)
@@ -264,7 +265,7 @@ static void plan_fused(smrt_vae* h) {
     if (h->fused && bytes > 48 * 1024 && fused_set_max_lds(bytes) != 0) { (void)hipGetLastError(); h->fused = false; }
     const char* pe = std::getenv("SMRT_HIP_PERSIST");
     h->persist_ok = h->fused && (pe ? std::atoi(pe) != 0 : true) && h->cfg.dropout_keep >= 1.0f;
-    if (h->persist_ok && bytes > 48 * 1024 && persist_set_max_lds(bytes) != 0) { (void)hipGetLastError(); h->persist_ok = false; }
+    if (h->persist_ok && bytes > 48 * 1024 && persist_set_max_lds(persist_pick_kernel(nullptr, 0), bytes) != 0) { (void)hipGetLastError(); h->persist_ok = false; }
 }
 
 // Workgroups of the persistent kernel for a mini-batch size; 0: this schedule does not take the persistent path.
@@ -510,6 +511,12 @@ static int ensure_train(smrt_vae* h, int rows) {
         }
         su[ns] = su[ns - 1];
         h->n_stage_u = ns;
+        h->pkernel = persist_pick_kernel(su, ns);
+        if (h->pkernel != persist_pick_kernel(nullptr, 0) && h->fplan.lds_total * (int)sizeof(float) > 48 * 1024 &&
+            persist_set_max_lds(h->pkernel, h->fplan.lds_total * (int)sizeof(float)) != 0) {
+            (void)hipGetLastError();
+            h->pkernel = persist_pick_kernel(nullptr, 0);
+        }
         HIPC(hipMemcpy(h->stage_u, su, (size_t)(ns + 1) * sizeof(StageU), hipMemcpyHostToDevice));
     }
     return 0;
@@ -607,7 +614,7 @@ static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_r
     if (!pdbg) { (void)hipMalloc((void**)&pdbg, 160 * 8); (void)hipMemset(pdbg, 0, 160 * 8); }
     a.dbg = pdbg;
 #endif
-    { ProfScope ps(h, PK_PERSIST); launch_persist_train(s, a, G + n_owner); }
+    { ProfScope ps(h, PK_PERSIST); launch_persist_train(s, h->pkernel ? h->pkernel : persist_pick_kernel(nullptr, 0), a, G + n_owner); }
 #ifdef SMRT_STAMPS
     {
         (void)hipStreamSynchronize(s);
@@ -1073,6 +1080,10 @@ int64_t smrt_vae_step_count(const smrt_vae* h) { return h ? h->steps : -1; }
 int smrt_vae_last_epoch_launches(const smrt_vae* h) { return h ? h->last_epoch_launches : -1; }
 
 int32_t smrt_persistent_budget(int32_t device) { return persist_budget(device); }
+int32_t smrt_vae_persistent_form(const smrt_vae* h) {
+    if (!h || !h->persist_ok || !h->pkernel) return 0;
+    return h->pkernel == persist_pick_kernel(nullptr, 0) ? 1 : 2;
+}
 int32_t smrt_vae_persistent_workgroups(const smrt_vae* h, int32_t batch_rows) {
     if (!h) return -1;
     if (!h->persist_ok || batch_rows > PERSIST_ROWS_MAX || batch_rows < 1) return 0;

@@ -122,8 +122,8 @@ struct StageCtx {
 // buffer (the weight-gradient side reads it).  The caller runs lds_barrier() after exec_stage, then (after a FK_FWD_HEADS
 // stage) reparam_after_heads().
 struct StageDec {
-    int nb_all, nn, N, N16, kind, act, trans, s_out, s_aux, bstep, bstride, Zq;     // (uniform)
-    int out_off, wrote_tail;                                                        // (uniform) FK_BWD_LATENT: tail to clear
+    int nb_all, nn, N, N16, kind, act, trans, s_out, s_aux, Zq;                     // (uniform)
+    int out_off, w_off;                                                             // (uniform)
     const float* ap;          // this lane's A fragment base (activations)
     const float* bp;          // this lane's weight fragment base, first column block
     float* o;                 // this lane's output element (row 4 q, column n) in the LDS tile, first column block
@@ -148,9 +148,7 @@ __device__ __forceinline__ StageDec decode_stage(const int4 d0, const int4 d1, c
     gfloat* gblk = (gfloat*)(((unsigned long long)(unsigned)UNI(d4.y) << 32) | (unsigned)UNI(d4.x)) + x.blk * NF * 16;
     StageDec s;
     s.nb_all = K16 >> 4; s.nn = nn; s.N = N; s.N16 = (N + 15) & ~15; s.kind = kind; s.act = act; s.trans = trans;
-    s.s_out = s_out; s.s_aux = s_aux; s.out_off = out_off;
-    s.bstep = trans ? 64 : (nn << 4);                                     // floats per 16 k
-    s.bstride = trans ? 128 * nn : 512;                                   // floats per 128 columns (the next column block of a wave)
+    s.s_out = s_out; s.s_aux = s_aux; s.out_off = out_off; s.w_off = w_off;
     const int n = wave * 16 + c;
     s.n = n;
     s.ap = lds + in_off + c * sin + 4 * q;
@@ -161,11 +159,12 @@ __device__ __forceinline__ StageDec decode_stage(const int4 d0, const int4 d1, c
     s.po = lds + aux_off + (4 * q) * s_aux + n;
     s.pb = lds + b_off + 4 * n;
     s.Zq = (4 * q) * x.s_z;
-    s.wrote_tail = 0;
     return s;
 }
 
-template <int TO_GLOBAL, int SK = -1, int SNB = 0, int SACT = -1>
+// SNT: the stage's padded output width in 16-column blocks (0: from the record).  With it a wave knows statically whether it
+// has a column block, and (with SNB) the image's column count is an immediate, so are the weight fragments' k-block offsets.
+template <int TO_GLOBAL, int SK = -1, int SNB = 0, int SACT = -1, int SNT = 0>
 __device__ __forceinline__ int exec_stage(const StageDec& s, const StageCtx& x, float& bce) {
     float* const lds = x.lds;
     const int wave = x.wave, q = x.q, tid = x.tid, rows_here = x.rows_here, Z = x.Z, s_z = x.s_z;
@@ -173,10 +172,16 @@ __device__ __forceinline__ int exec_stage(const StageDec& s, const StageCtx& x, 
     const float* const es = x.es;
     const int kind = SK >= 0 ? SK : s.kind, act = SACT >= 0 ? SACT : s.act;
     const int trans = SK >= 0 ? (SK >= FK_BWD_ACT ? 1 : 0) : s.trans;
-    const int N = s.N, N16 = s.N16, s_out = s.s_out, s_aux = s.s_aux, bstep = s.bstep;
+    const int N = s.N, N16 = SNT > 0 ? 16 * SNT : s.N16, s_out = s.s_out, s_aux = s.s_aux;
+    // the image's column count is rup16(fan-out) + 1: the padded OUTPUT width forward, the padded K extent backward
+    constexpr bool NN_STATIC = SK >= 0 && ((SK >= FK_BWD_ACT) ? SNB > 0 : SNT > 0);
+    const int nn = NN_STATIC ? 16 * ((SK >= FK_BWD_ACT) ? SNB : SNT) + 1 : s.nn;
+    const int bstep = trans ? 64 : (nn << 4);
     XST(0);
     int n = s.n;
     const float* bp0 = s.bp;
+    if constexpr (NN_STATIC)        // (the same address as decode's, with nn an immediate)
+        bp0 = trans ? lds + (((__mul24(n >> 2, nn) + 4 * q) << 2) + (n & 3) + s.w_off) : lds + (((q * nn + n) << 2) + s.w_off);
     float* o = s.o;
     gfloat* g = s.g;
     const float* po = s.po;
@@ -295,10 +300,14 @@ __device__ __forceinline__ int exec_stage(const StageDec& s, const StageCtx& x, 
             }
         }
     };
+    if constexpr (SNT > 0 && SNT <= FWAVES) {
+        if (wave < SNT) block();                        // at most one block per wave
+    } else {
 #pragma unroll 1
-    for (int n0 = wave * 16; n0 < N16; n0 += 16 * FWAVES) {
-        block();
-        n += 16 * FWAVES; bp0 += s.bstride; o += 16 * FWAVES; g += 16 * FWAVES * 16; po += 16 * FWAVES; pbias += 4 * 16 * FWAVES;
+        for (int n0 = wave * 16; n0 < N16; n0 += 16 * FWAVES) {
+            block();
+            n += 16 * FWAVES; bp0 += (trans ? 128 * nn : 512); o += 16 * FWAVES; g += 16 * FWAVES * 16; po += 16 * FWAVES; pbias += 4 * 16 * FWAVES;
+        }
     }
     XST(3);
     if (kind == FK_BWD_LATENT) {
@@ -331,9 +340,7 @@ __device__ __forceinline__ StageDec decode_stage_u(const i32x16 u, const StageCt
     const int nn = u[4], packed = u[6];
     const int trans = (packed >> 16) & 255;
     s.nb_all = u[2]; s.nn = nn; s.N = u[5]; s.N16 = u[7]; s.kind = packed & 255; s.act = (packed >> 8) & 255; s.trans = trans;
-    s.s_out = u[9]; s.s_aux = u[12]; s.out_off = u[8];
-    s.bstep = trans ? 64 : (nn << 4);
-    s.bstride = trans ? 128 * nn : 512;
+    s.s_out = u[9]; s.s_aux = u[12]; s.out_off = u[8]; s.w_off = u[3];
     s.n = n;
     s.ap = lds + (__mul24(c, u[1]) + 4 * q + u[0]);
     s.bp = trans ? lds + (((__mul24(n >> 2, nn) + 4 * q) << 2) + (n & 3) + u[3])
@@ -344,7 +351,6 @@ __device__ __forceinline__ StageDec decode_stage_u(const i32x16 u, const StageCt
     gfloat* gout = (gfloat*)(((unsigned long long)(unsigned)u[15] << 32) | (unsigned)u[14]);
     s.g = gout + (x.blk * u[13] + (n * 16 + 4 * q));
     s.Zq = (4 * q) * x.s_z;
-    s.wrote_tail = 0;
     return s;
 }
 

@@ -382,8 +382,10 @@ struct PersistArgs {
     float lr, l2, gmin, gmax;
     unsigned long long* dbg;              // diagnostic builds only (-DSMRT_STAMPS): phase time stamps, step 4
 };
-void launch_persist_train(hipStream_t s, const PersistArgs& a, int n_workgroups);
-int  persist_set_max_lds(int bytes);
+typedef void (*persist_kernel_t)(const PersistArgs);
+persist_kernel_t persist_pick_kernel(const StageU* stages, int n_stages);   // the instantiation written out for this table, else the generic kernel
+void launch_persist_train(hipStream_t s, persist_kernel_t k, const PersistArgs& a, int n_workgroups);
+int  persist_set_max_lds(persist_kernel_t k, int bytes);
 int  persist_owner_workgroups(int total_tiles);     // one owner wave per 16x16 weight-gradient tile, 4 per workgroup
 int  persist_max_owner_workgroups();               // one flag word per owner workgroup
 

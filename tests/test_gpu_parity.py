@@ -471,6 +471,46 @@ def test_persistent_epochs_match_two_kernel_path_and_oracle(monkeypatch, kernel_
     hp.close(); h2.close()
 
 
+@pytest.mark.parametrize("D,hidden,Z,form", [
+    (64, [128], 16, 2),        # the bench net: 4 / 8 / 1 / 2 sixteen-wide blocks (features / hidden / latent / both heads)
+    (16, [32], 8, 2),          # the smallest instantiation: 1 / 2 / 1 / 1
+    (30, [60], 12, 2),         # ragged widths inside 32 / 64 / 16 / 32
+    (128, [64], 32, 2),        # 8 / 4 / 2 / 4
+    (100, [64], 16, 1),        # 112 features = 7 blocks: no instantiation, the generic kernel
+    (30, [20, 12], 5, 1),      # two hidden layers: the generic kernel
+])
+def test_persistent_kernel_written_out_per_shape_equals_the_generic_one(monkeypatch, kernel_path, D, hidden, Z, form):
+    """persist_seq.hip: for one-hidden-layer sigmoid VAEs of the common padded widths the stage sequence is written out (no
+    loop, no switch, structure-specialised bodies).  Same arithmetic in the same order as the generic kernel: three epochs
+    with a ragged tail leave bit-identical costs, parameters and optimizer slots; and the table of instantiations is what
+    include/smrt_hip.h says it is."""
+    if kernel_path != "fused":
+        pytest.skip("the persistent kernel belongs to the LDS-resident (fused) path")
+    monkeypatch.setenv("SMRT_HIP_PERSIST", "1")
+    rs = np.random.RandomState(D + Z)
+    n, B = 300, 128
+    X = rs.uniform(0, 1, size=(n, D))
+    o = _oracle(D, hidden, Z, act="sigmoid", opt="adam", lr=0.01, l2=1e-4, clip=True, seed=11, rs=rs)
+    out = []
+    for seq in (None, "0"):
+        if seq is None:
+            monkeypatch.delenv("SMRT_HIP_PERSIST_SEQ", raising=False)
+        else:
+            monkeypatch.setenv("SMRT_HIP_PERSIST_SEQ", seq)
+        h = _handle(D, hidden, Z, act="sigmoid", opt="adam", lr=0.01, l2=1e-4, clip=True, seed=11, max_batch=B)
+        h.set_params(flatten_params(o.params))
+        costs, _ = h.train_epochs(X, B, 3)
+        assert h.last_epoch_launches == 2
+        assert h.persistent_form == (form if seq is None else 1)
+        out.append((np.asarray(costs), h.get_params(), h.get_opt_state(0), h.get_opt_state(1)))
+        h.close()
+    for a, b, what in zip(out[0], out[1], ("costs", "parameters", "slot 0", "slot 1")):
+        np.testing.assert_array_equal(a, b, err_msg=what)
+    o.fit(X, n_epochs=3, batch_size=B)
+    np.testing.assert_allclose(out[0][0], np.asarray(o.epoch_costs_, np.float32), rtol=RTOL)
+    _close(out[0][1], flatten_params(o.params), "written-out kernel vs oracle")
+
+
 def test_persistent_early_stopping_and_ineligible_nets(monkeypatch, kernel_path):
     """Early stopping reads the cost after every persistent launch; dropout nets keep the two-kernel step."""
     if kernel_path != "fused":
