@@ -12,12 +12,12 @@
 namespace smrt {
 
 template <int DB, int ZB, int Z2B>
-__global__ __launch_bounds__(FTHREADS) void SEQ_CAT(persist_seq_kernel_hb, SEQ_HB)(const PersistArgs a) {
+__global__ __launch_bounds__(FTHREADS) void SEQ_CAT(persist_train_seq_hb, SEQ_HB)(const PersistArgs a) {
     persist_train_body<SeqVae1<DB, SEQ_HB, ZB, Z2B>>(a);
 }
 
 persist_kernel_t SEQ_CAT(persist_seq_kernel_h, SEQ_HB)(int db, int zb, int z2b) {
-#define SEQ_ONE(DB_, ZB_, Z2B_) if (db == DB_ && zb == ZB_ && z2b == Z2B_) return SEQ_CAT(persist_seq_kernel_hb, SEQ_HB)<DB_, ZB_, Z2B_>;
+#define SEQ_ONE(DB_, ZB_, Z2B_) if (db == DB_ && zb == ZB_ && z2b == Z2B_) return SEQ_CAT(persist_train_seq_hb, SEQ_HB)<DB_, ZB_, Z2B_>;
 #define SEQ_D(DB_) SEQ_ONE(DB_, 1, 1) SEQ_ONE(DB_, 1, 2) SEQ_ONE(DB_, 2, 4)
     SEQ_D(1) SEQ_D(2) SEQ_D(4) SEQ_D(8)
 #undef SEQ_D
