@@ -49,7 +49,8 @@ __device__ __forceinline__ void store4_sc1(float* p, float v) {        // global
 // only grows).  Lane i polls flags i, i + 64, ...: one relaxed sc1 load per lane and round trip, a short sleep between.
 // false: gave up (time-out here, or another workgroup's).  A single counter that every producer adds to cost more: the
 // adds of one step serialise on their line in L2 (11-13 ns each, 28 owners) and the add is a round trip where the flag is
-// a fire-and-forget store.  (Keeping four polls in flight to see a change a quarter round trip earlier was 3 % SLOWER.)
+// a fire-and-forget store.  (Keeping four polls in flight to see a change a quarter round trip earlier was 3 % SLOWER in round 2; round 3 tried them STAGGERED a
+// fraction of a round trip apart, oldest waited for with a counted vmcnt: 13.36 us per mini-batch with one poll, 13.64 with two, 13.95 with four.)
 constexpr int PCNT_FG = 0, PCNT_FW = 64, PCNT_ERR = 192;      // word offsets in PersistArgs::cnt (256 words, zeroed per launch)
 constexpr int PCNT_FW_MAX = 128;
 __device__ __forceinline__ bool wait_flags(unsigned* f, int n, unsigned target, unsigned* err, int lane) {
