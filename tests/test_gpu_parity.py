@@ -511,6 +511,48 @@ def test_persistent_kernel_written_out_per_shape_equals_the_generic_one(monkeypa
     _close(out[0][1], flatten_params(o.params), "written-out kernel vs oracle")
 
 
+def test_every_written_out_instantiation_equals_the_generic_kernel(monkeypatch, kernel_path):
+    """All 36 instantiations of persist_seq.hip (features 16 / 32 / 64 / 128 x hidden 32 / 64 / 128 x latent <= 8 / 16 / 32), each at a
+    ragged width inside its padded one: two epochs with a ragged tail, bit-identical to the generic persistent kernel.  Shapes
+    whose weights do not fit in LDS are not on this path at all (persistent_form 0) and are skipped."""
+    if kernel_path != "fused":
+        pytest.skip("the persistent kernel belongs to the LDS-resident (fused) path")
+    monkeypatch.setenv("SMRT_HIP_PERSIST", "1")
+    n, B, ran = 150, 64, 0
+    for D16 in (16, 32, 64, 128):
+        for H16 in (32, 64, 128):
+            for Z, zmax in ((8, 8), (16, 16), (32, 32)):
+                D, H, Zr = D16 - 3, H16 - 5, zmax - (1 if zmax > 8 else 2)          # ragged inside the padded widths
+                rs = np.random.RandomState(D16 + H16 + Z)
+                X = rs.uniform(0, 1, size=(n, D))
+                p0 = None
+                out = []
+                for seq in (None, "0"):
+                    if seq is None:
+                        monkeypatch.delenv("SMRT_HIP_PERSIST_SEQ", raising=False)
+                    else:
+                        monkeypatch.setenv("SMRT_HIP_PERSIST_SEQ", seq)
+                    h = _handle(D, [H], Zr, act="sigmoid", opt="rms_prop", lr=0.01, l2=1e-4, clip=True, seed=3, max_batch=B)
+                    if p0 is None:
+                        p0 = (rs.normal(size=h.n_params) * 0.1).astype(np.float32)
+                    h.set_params(p0)
+                    form = h.persistent_form
+                    if form == 0:
+                        h.close()
+                        break
+                    assert form == (2 if seq is None else 1), (D, H, Zr, form)
+                    costs, _ = h.train_epochs(X, B, 2)
+                    assert h.last_epoch_launches == 2
+                    out.append((np.asarray(costs), h.get_params(), h.get_opt_state(0)))
+                    h.close()
+                if len(out) == 2:
+                    ran += 1
+                    for a, b, what in zip(out[0], out[1], ("costs", "parameters", "slot 0")):
+                        np.testing.assert_array_equal(a, b, err_msg="%s of %d-%d-%d" % (what, D, H, Zr))
+                    assert np.isfinite(out[0][0]).all()
+    assert ran >= 30, ran
+
+
 def test_persistent_early_stopping_and_ineligible_nets(monkeypatch, kernel_path):
     """Early stopping reads the cost after every persistent launch; dropout nets keep the two-kernel step."""
     if kernel_path != "fused":
