@@ -110,7 +110,7 @@ struct smrt_vae {
     int n_stage_u = 0;
     persist_kernel_t pkernel = nullptr;   // the persistent kernel for this net: a sequence-specialised instantiation or the generic one
     DwRec* dwrec = nullptr;          // small-batch fused weight-gradient + update launch: 32x32 tile records, then 64x64 ones
-    int n_rec32 = 0, n_rec64 = 0;
+    int n_rec32 = 0;
     // persistent whole-epoch kernel (persist_train.hip)
     bool persist_ok = false;         // the net qualifies (fits in LDS, no dropout, VAE)
     unsigned* pcnt = nullptr;        // producer flags + error word (256 words)
@@ -437,7 +437,7 @@ static int ensure_train(smrt_vae* h, int rows) {
         carve(a, &h->Eb, (size_t)cap * rup4(h->Z));
         carve(a, &h->bce_p, (size_t)nb);
         carve(a, &h->kl_p, (size_t)std::max(reparam_blocks(cap, h->Z), (cap + 15) / 16));
-        carve(a, &h->dwrec, (size_t)(h->n_rec32 + h->n_rec64));
+        carve(a, &h->dwrec, (size_t)h->n_rec32);
         if (h->fused) {
             for (int l = 0; l < h->NL; ++l) {
                 carve(a, &h->outT[l], (l < h->NL - 1) ? (size_t)cap * rup16(h->lay[l].fo) : 0);
@@ -449,10 +449,9 @@ static int ensure_train(smrt_vae* h, int rows) {
             carve(a, &h->stage_u, (size_t)(2 * MAX_LAYERS + 1));
         }
     };
-    h->n_rec32 = h->n_rec64 = 0;
+    h->n_rec32 = 0;
     for (int l = 0; l < h->NL; ++l) {
         h->n_rec32 += ((h->lay[l].fi + 1 + 31) / 32) * ((h->lay[l].fo + 31) / 32);
-        h->n_rec64 += ((h->lay[l].fi + 1 + 63) / 64) * ((h->lay[l].fo + 63) / 64);
     }
     Arena dry;
     layout(dry);
@@ -462,21 +461,21 @@ static int ensure_train(smrt_vae* h, int rows) {
     h->cap_rows = cap;
     {   // tile records of the small-batch fused weight-gradient + update launch (the workspace pointers are fixed from here on)
         std::vector<DwRec> recs;
-        for (int t : {32, 64})
-            for (int l = 0; l < h->NL; ++l) {
-                const LayerI& y = h->lay[l];
-                const bool from_x = (l == 0), from_z = (l == h->hl + 1 && !h->ae);
-                for (int m0 = 0; m0 <= y.fi; m0 += t)
-                    for (int n0 = 0; n0 < y.fo; n0 += t) {
-                        DwRec r{};
-                        r.A = from_x ? nullptr : (from_z ? h->Zb : h->out[l - 1]);
-                        r.lda = from_x ? 0 : (from_z ? rup4(h->Z) : h->lay[l - 1].ld);
-                        r.B = h->dpre[l]; r.ldb = y.ld; r.ldc = y.ld; r.off = y.off; r.fi = y.fi; r.fo = y.fo;
-                        r.m0 = m0; r.n0 = n0; r.l2 = y.l2;
-                        recs.push_back(r);
-                    }
-            }
-        if ((int)recs.size() != h->n_rec32 + h->n_rec64) return fail(-4, "internal: weight-gradient record count mismatch");
+        const int t = 32;
+        for (int l = 0; l < h->NL; ++l) {
+            const LayerI& y = h->lay[l];
+            const bool from_x = (l == 0), from_z = (l == h->hl + 1 && !h->ae);
+            for (int m0 = 0; m0 <= y.fi; m0 += t)
+                for (int n0 = 0; n0 < y.fo; n0 += t) {
+                    DwRec r{};
+                    r.A = from_x ? nullptr : (from_z ? h->Zb : h->out[l - 1]);
+                    r.lda = from_x ? 0 : (from_z ? rup4(h->Z) : h->lay[l - 1].ld);
+                    r.B = h->dpre[l]; r.ldb = y.ld; r.ldc = y.ld; r.off = y.off; r.fi = y.fi; r.fo = y.fo;
+                    r.m0 = m0; r.n0 = n0; r.l2 = y.l2;
+                    recs.push_back(r);
+                }
+        }
+        if ((int)recs.size() != h->n_rec32) return fail(-4, "internal: weight-gradient record count mismatch");
         HIPC(hipMemcpy(h->dwrec, recs.data(), recs.size() * sizeof(DwRec), hipMemcpyHostToDevice));
     }
     if (h->fused) {
@@ -871,14 +870,11 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         { ProfScope ps(h, PK_DW); launch_fused_dw_slab(s, d, splits); } ++launches;
     } else {
         // Small mini-batches, a full step, no dropout: the weight-gradient launch applies the update itself (small_gemm.hip:
-        // small_dw_opt) -- one launch fewer per mini-batch, no gradient slab, no optimizer sweep.  32x32 tiles, or 64x64 on
-        // request (SMRT_HIP_DW64=1: half the operand traffic, measured no faster).
-        static const int dw64_env = []() { const char* e = std::getenv("SMRT_HIP_DW64"); return e ? std::atoi(e) : 0; }();
+        // small_dw_opt) -- one launch fewer per mini-batch, no gradient slab, no optimizer sweep.
         static const bool dwopt_env = []() { const char* e = std::getenv("SMRT_HIP_DW_OPT"); return e ? std::atoi(e) != 0 : true; }();
         if (small && mode == 0 && !h->has_drop && dwopt_env && h->n_rec32 <= h->l2_cap) {
-            const bool dw64 = dw64_env != 0 && small_dw64_available();
             DwFusedArgs d{};
-            d.tiles = dw64 ? h->dwrec + h->n_rec32 : h->dwrec; d.total_tiles = dw64 ? h->n_rec64 : h->n_rec32; d.rows = rows;
+            d.tiles = h->dwrec; d.total_tiles = h->n_rec32; d.rows = rows;
             d.X = X; d.ldx = ldx;
             d.W = h->W; d.s0 = h->s0; d.s1 = h->s1; d.grad_out = o.grad_out; d.l2_partials = h->l2_p; d.st = h->st;
             d.opt = h->cfg.optimizer; d.clip = h->cfg.clip; d.has_l2 = h->has_l2 ? 1 : 0;
@@ -891,7 +887,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             if (!ddbg) { (void)hipMalloc((void**)&ddbg, 64 * 8); (void)hipMemset(ddbg, 0, 64 * 8); }
             d.dbg = ddbg;
 #endif
-            { ProfScope ps(h, PK_DW); if (dw64) launch_small_dw64_opt(s, d); else launch_small_dw_opt(s, d); } ++launches;
+            { ProfScope ps(h, PK_DW); launch_small_dw_opt(s, d); } ++launches;
 #ifdef SMRT_STAMPS
             {
                 (void)hipStreamSynchronize(s);

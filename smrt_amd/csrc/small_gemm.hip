@@ -867,185 +867,8 @@ void launch_small_dw_opt(hipStream_t s, const DwFusedArgs& a) {
     else               SMRT_LAUNCH(small_dw_opt_kernel<8>, dim3(a.total_tiles), dim3(256), 0, s, a);
 }
 
-// ------------------------------------------------------------------ the same launch on 64x64 tiles
-// 780 tiles of 32x32 re-read every operand panel 25 / 15 times: 25 MB of activations and gradients through the CUs' L1s
-// for 2.9 MB of weights, three workgroups a CU.  A 64x64 tile halves that traffic and N1's 224 tiles are one workgroup per
-// CU.  v_mfma_f32_16x16x4_f32 with BOTH operands mn-contiguous ([k][m] inputs, [k][n] gradients): lane i loads four
-// consecutive m (n) of row k = block + 4 q + s as ONE 16-byte load (16 lanes x 16 bytes contiguous) and accumulator
-// (mt, nt) holds rows m0 + 4 (4 q + r) + mt, columns n0 + 4 i + nt -- the interleave is undone when the four waves' partial
-// tiles (K split by k-block, as everywhere here) meet in LDS.  The tile's weights and slots are requested between the
-// last MFMA and that reduction.  Chosen when the net has at least DW64_MIN_TILES such tiles (smaller nets keep the
-// parallelism of 32x32 tiles).
-constexpr int DW64 = 64, DW64_RS = 65, DW64_SG = 2;
-struct Frag64 { f32x4v a[4], b[4]; };        // [k step]: four consecutive m / n of row k4 + s
-
-__device__ __forceinline__ void small_dw64_opt_body(const DwFusedArgs& a) {
-    extern __shared__ float red64[];                                  // 4 x 64 x DW64_RS floats
-    __shared__ float sred[4];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 15, q = lane >> 4;
-    const int t = blockIdx.x;
-    const DwRec L = a.tiles[t];                                          // (uniform index: one scalar load)
-    const float* Ap = L.A ? L.A : a.X;
-    const long lda = L.A ? (long)L.lda : a.ldx;
-    const int m0 = L.m0, n0 = L.n0;
-    const int K = a.rows, fi = L.fi, fo = L.fo;
-    float alpha = 0.f;
-    if (a.opt == 2) alpha = a.lr * sqrtf(1.0f - a.st->b2pow) / (1.0f - a.st->b1pow);
-    if (a.advance && t == 0 && tid == 0) {       // (never under Adam, whose blocks all read the beta powers above)
-        a.st->step += 1;
-        a.st->b1pow *= 0.9f;
-        a.st->b2pow *= 0.999f;
-    }
-    const int nkb = (K + 15) >> 4;
-    const int mine = (nkb - wave + 3) >> 2;
-    // this lane's four m / four n; loads come from clamped, always-valid quads (a row of the operand is a multiple of 4 long)
-    const int mq = m0 + 4 * i, nq = n0 + 4 * i;
-    const float* pa = Ap + min(mq, (int)lda - 4);
-    const float* pb = L.B + min(nq, L.ldb - 4);
-    const bool edge = (m0 + DW64 > fi) || (n0 + DW64 > fo) || ((K & 15) != 0);     // (the ones row makes every last row tile an edge)
-    f32x4v acc[4][4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    Frag64 cur[DW64_SG], nxt[DW64_SG];
-    auto fetch = [&](int first, Frag64 (&x)[DW64_SG]) {
-#pragma unroll
-        for (int j = 0; j < DW64_SG; ++j) {
-            const int k4 = ((first + j) * 4 + wave) * 16 + 4 * q;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const long r = (long)min(k4 + s2, K - 1);
-                x[j].a[s2] = *reinterpret_cast<const f32x4v*>(pa + r * lda);
-                x[j].b[s2] = *reinterpret_cast<const f32x4v*>(pb + r * L.ldb);
-            }
-        }
-    };
-    auto mask = [&](int first, Frag64 (&x)[DW64_SG]) {
-        if (!edge) return;
-#pragma unroll
-        for (int j = 0; j < DW64_SG; ++j) {
-            const int k4 = ((first + j) * 4 + wave) * 16 + 4 * q;
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const bool kin = k4 + s2 < K;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int m = mq + c, n = nq + c;
-                    x[j].a[s2][c] = kin ? (m < fi ? x[j].a[s2][c] : (m == fi ? 1.f : 0.f)) : 0.f;     // m == fi: the ones index (bias)
-                    x[j].b[s2][c] = (kin && n < fo) ? x[j].b[s2][c] : 0.f;
-                }
-            }
-        }
-    };
-    if (mine > 0) { fetch(0, cur); mask(0, cur); }
-#pragma unroll 1
-    for (int b0 = 0; b0 < mine; b0 += DW64_SG) {
-        const bool more = b0 + DW64_SG < mine;
-        if (more) fetch(b0 + DW64_SG, nxt);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        const int cnt = min(DW64_SG, mine - b0);
-#pragma unroll
-        for (int j = 0; j < DW64_SG; ++j) {
-            if (j < cnt) {
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[j].a[s2][mt], cur[j].b[s2][nt], acc[mt][nt], 0, 0, 0);
-            }
-        }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < DW64_SG; ++j) cur[j] = nxt[j];
-            mask(b0 + DW64_SG, cur);
-        }
-    }
-    // the tile's weights and slots: four quads per thread (quad e = tid + 256 u: row e / 16, columns 4 (e % 16) ..), requested
-    // now so that they arrive under the reduction
-    float4 w4[4], s04[4], s14[4];
-    long ix[4];
-    bool inq[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int e = tid + 256 * u, row = m0 + (e >> 4), col0 = n0 + (e & 15) * 4;
-        inq[u] = row <= fi && col0 < L.ldc;
-        ix[u] = L.off + (long)min(row, fi) * L.ldc + min(col0, L.ldc - 4);
-        w4[u] = *reinterpret_cast<const float4*>(a.W + ix[u]);
-        s04[u] = *reinterpret_cast<const float4*>(a.s0 + ix[u]);
-        s14[u] = *reinterpret_cast<const float4*>(a.s1 + ix[u]);
-    }
-    float* mine_red = red64 + wave * (DW64 * DW64_RS);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mine_red[(4 * (4 * q + r) + mt) * DW64_RS + 4 * i + nt] = acc[mt][nt][r];
-    __syncthreads();
-    const bool has_s0 = a.opt != 0 && a.opt != 5;
-    const bool has_s1 = a.opt == 1 || a.opt == 2 || a.opt == 4;
-    float l2acc = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int e = tid + 256 * u, lr = e >> 4, c4 = (e & 15) * 4, row = m0 + lr;
-        float gv[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float* p = red64 + lr * DW64_RS + c4 + c;
-            gv[c] = (p[0] + p[DW64 * DW64_RS]) + (p[2 * DW64 * DW64_RS] + p[3 * DW64 * DW64_RS]);
-        }
-        if (inq[u]) {
-            float wv[4] = {w4[u].x, w4[u].y, w4[u].z, w4[u].w};
-            float s0v[4] = {s04[u].x, s04[u].y, s04[u].z, s04[u].w}, s1v[4] = {s14[u].x, s14[u].y, s14[u].z, s14[u].w};
-            if (a.has_l2 && L.l2 && row < fi) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    gv[c] += a.l2 * wv[c];                               // tf.nn.l2_loss on the layer's weights, base.py:129
-                    l2acc += 0.5f * wv[c] * wv[c];
-                }
-            }
-            if (a.grad_out) *reinterpret_cast<float4*>(a.grad_out + ix[u]) = make_float4(gv[0], gv[1], gv[2], gv[3]);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float gj = gv[c];
-                if (a.clip) gj = tf_clip(gj, a.gmin, a.gmax);           // tf.clip_by_value, base.py:144
-                wv[c] = opt_update_ieee(a.opt, a.lr, alpha, wv[c], gj, s0v[c], s1v[c]);
-            }
-            *reinterpret_cast<float4*>(a.W + ix[u]) = make_float4(wv[0], wv[1], wv[2], wv[3]);
-            if (has_s0) *reinterpret_cast<float4*>(a.s0 + ix[u]) = make_float4(s0v[0], s0v[1], s0v[2], s0v[3]);
-            if (has_s1) *reinterpret_cast<float4*>(a.s1 + ix[u]) = make_float4(s1v[0], s1v[1], s1v[2], s1v[3]);
-        }
-    }
-    const float tot = block_sum_256(l2acc, sred);
-    if (tid == 0) a.l2_partials[t] = tot;
-}
-
-__global__ __launch_bounds__(256, 2) void small_dw64_opt_kernel(const DwFusedArgs a) { small_dw64_opt_body(a); }
-__global__ __launch_bounds__(256, 2) void small_dw64_opt_multi(const MultiSlot<DwFusedArgs>* __restrict__ t) {
-    const MultiSlot<DwFusedArgs>& s = t[blockIdx.z];
-    if (blockIdx.x >= s.gx) return;
-    small_dw64_opt_body(s.a);
-}
-static MultiReg<DwFusedArgs> reg_small_dw64_opt(small_dw64_opt_kernel, small_dw64_opt_multi);
-constexpr int DW64_LDS = 4 * DW64 * DW64_RS * (int)sizeof(float);
-static int dw64_lds_ready() {
-    static const int rc = []() {
-        int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(small_dw64_opt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DW64_LDS);
-        if (r == 0) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(small_dw64_opt_multi), hipFuncAttributeMaxDynamicSharedMemorySize, DW64_LDS);
-        if (r != 0) (void)hipGetLastError();
-        return r;
-    }();
-    return rc;
-}
-bool small_dw64_available() { return dw64_lds_ready() == 0; }
-void launch_small_dw64_opt(hipStream_t s, const DwFusedArgs& a) {
-    SMRT_LAUNCH(small_dw64_opt_kernel, dim3(a.total_tiles), dim3(256), (size_t)DW64_LDS, s, a);
-}
+// (The same launch on 64x64 tiles -- 16x16x4 MFMAs, both operands mn-contiguous, panels shared through LDS: half the operand
+// traffic -- was built and measured in round 3: N1 alone 8.0 us per launch either way, the grouped 8-class step of C3 5.75 -> 6.2 ms
+// per epoch.  Removed.)
 
 }  // namespace smrt

@@ -169,7 +169,7 @@ struct DwArgs {
     int ycum[33];        // tiled kernel: work units in front of K-range index y (units are ordered range-major)
 };
 
-// Fused weight-gradient + update launch of small mini-batches (small_gemm.hip: small_dw_opt / small_dw64_opt): one record
+// Fused weight-gradient + update launch of small mini-batches (small_gemm.hip: small_dw_opt): one record
 // per output tile, built once per workspace (api.hip: ensure_train), read by its workgroup with ONE 64-byte scalar load.
 struct DwRec {
     const float* A;      // layer input [rows][lda]; NULL: the mini-batch itself (DwFusedArgs::X, ldx), which moves every step
@@ -418,8 +418,6 @@ void launch_small_gemm(hipStream_t s, int kind, int epi, const GemmArgs& a);
 int  small_gemm_blocks(const GemmArgs& a);
 void launch_small_dw(hipStream_t s, const DwArgs& a);
 void launch_small_dw_opt(hipStream_t s, const DwFusedArgs& a);
-void launch_small_dw64_opt(hipStream_t s, const DwFusedArgs& a);     // the same on 64x64 tiles
-bool small_dw64_available();
 int  gemm_grid_blocks(int kind, const GemmArgs& a);          // number of blocks (= BCE partial count)
 void launch_dw(hipStream_t s, const DwArgs& a, bool big);
 void launch_optimizer(hipStream_t s, const OptArgs& a, int* n_blocks_out);
