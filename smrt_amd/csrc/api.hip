@@ -76,6 +76,8 @@ struct smrt_vae {
     float* outT[MAX_LAYERS] = {nullptr};
     float* dpreT[MAX_LAYERS] = {nullptr};
     float *XT = nullptr, *ZT = nullptr;
+    float* xt_all = nullptr; size_t xt_all_cap = 0;      // the epoch's X, blocked transposed once per train_epochs call (persistent path)
+    bool xt_all_on = false;
     float *bce_p = nullptr, *kl_p = nullptr, *l2_p = nullptr;
     int n_l2 = 0, l2_cap = 0;            // l2 partials of the optimizer sweep; capacity of l2_p
     float* cost_dev = nullptr; long cost_cap = 0;
@@ -594,6 +596,7 @@ static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_r
     a.X = X; a.ldx = ldx; a.n_rows = n_rows; a.batch = batch; a.n_steps = (int)((n_rows + batch - 1) / batch);
     a.Wimg = h->Wimg; a.img_total = f.img_total; a.W = h->W; a.s0 = h->s0; a.s1 = h->s1;
     a.tiles = h->tile_tab; a.total_tiles = h->tiles16; a.XT = h->XT; a.Zb_g = h->ZT; a.cap_blocks = h->cap_rows / 16;
+    a.XT_all = h->xt_all_on ? h->xt_all : nullptr;
     a.cnt = h->pcnt;
     a.lds_x = f.lds_x; a.s_x = f.s_x; a.lds_z = f.lds_z; a.lds_e = f.lds_e; a.s_z = f.s_z; a.lds_total = f.lds_total;
     a.seed = h->cfg.seed; a.st = h->st; a.lo = h->cfg.bce_lo; a.hi = h->cfg.bce_hi;
@@ -1062,6 +1065,7 @@ void smrt_vae_destroy(smrt_vae* h) {
     float* ibufs[] = {h->ibuf[0], h->ibuf[1], h->izb};
     for (float* b : ibufs) if (b) (void)hipFree(b);
     if (h->cost_pin) (void)hipHostFree(h->cost_pin);
+    if (h->xt_all) (void)hipFree(h->xt_all);
     if (h->err_pin) (void)hipHostFree(h->err_pin);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->prof_pool) (void)hipEventDestroy(e);
@@ -1170,6 +1174,7 @@ int smrt_vae_set_dropout_masks(smrt_vae* h, const float* host_flat, int64_t n) {
 static int ensure_cost(smrt_vae* h, long n) {
     if (n > h->cost_pin_cap) {
         if (h->cost_pin) (void)hipHostFree(h->cost_pin);
+    if (h->xt_all) (void)hipFree(h->xt_all);
         if (h->err_pin) (void)hipHostFree(h->err_pin);
         h->cost_pin = nullptr; h->err_pin = nullptr; h->cost_pin_cap = 0;
         HIPC(hipHostMalloc((void**)&h->cost_pin, sizeof(float) * n, hipHostMallocDefault));
@@ -1250,6 +1255,25 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     const char* nf_env = std::getenv("SMRT_HIP_PERSIST_NO_FALLBACK");
     const bool no_fallback = nf_env && std::atoi(nf_env) != 0;
     if (PG) HIPC(hipMemsetAsync(h->pcnt + 192, 0, 64 * sizeof(unsigned), h->stream));      // the sticky error word: once per call
+    // X does not change during the call: its blocked-transposed form (the first layer's weight-gradient operand) is built once,
+    // in front of the epochs, instead of being published by the compute workgroups every step -- when it fits the cap
+    // (SMRT_HIP_XT_ALL_MB, default 1024; 0 keeps the per-step form)
+    h->xt_all_on = false;
+    if (PG) {
+        const char* xe = std::getenv("SMRT_HIP_XT_ALL_MB");
+        const size_t cap_mb = xe ? (size_t)std::max(0, std::atoi(xe)) : 1024;
+        const size_t need = (size_t)nb * (size_t)PG * (size_t)rup16(h->D) * 16;           // floats
+        if (need * sizeof(float) <= (cap_mb << 20) && need * sizeof(float) < (size_t(1) << 32)) {
+            if (need > h->xt_all_cap) {
+                HIPC(hipStreamSynchronize(h->stream));
+                h->xt_all_cap = 0;
+                TRY(dalloc(&h->xt_all, need, h->stream));
+                h->xt_all_cap = need;
+            }
+            launch_xt_all(h->stream, X_dev, ldx, n_rows, batch_size, PG, h->D, h->xt_all);
+            h->xt_all_on = true;
+        }
+    }
     int cur_epoch = 0;
 
     // Enqueue one epoch (every contiguous batch, ragged tail last: sklearn gen_batches, base.py:198-199).

@@ -124,11 +124,26 @@ __device__ __forceinline__ void owner_role(const PersistArgs& a, int* go_flag, f
     const __amdgpu_buffer_rsrc_t r_img = make_rsrc(a.Wimg, (unsigned)(a.img_total * 4));
     const unsigned offA = ((unsigned)mA * 16u + 4u * q) * 4u, offB = ((unsigned)nB * 16u + 4u * q) * 4u;
     const bool l2on = a.has_l2 && T.l2;
+    // First-layer tiles when the epoch's X was transposed once in front of the launches (XT_all): their A operand is not a
+    // hand-off at all -- an earlier kernel wrote it -- so its fragments are requested BEFORE the wait for the rows (plain loads),
+    // and only the dPre fragments are left for the round trip behind the flag.
+    const bool xall = live && a.XT_all != nullptr && T.A == a.XT;           // (wave-uniform)
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.XT_all, (unsigned)a.n_steps * (unsigned)G * (unsigned)NFA * 64u);
 
     for (int step = 0; step < a.n_steps; ++step) {
         const int rows = (int)min((long)a.batch, a.n_rows - (long)step * a.batch);
         const int n_active = (rows + FTM - 1) / FTM;
         const bool last = step == a.n_steps - 1;
+        f32x4 ax[8];
+        if (xall) {
+            const unsigned sbase = (unsigned)step * (unsigned)G * (unsigned)NFA * 64u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned jb = (unsigned)min(j, n_active - 1);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rX, sbase + jb * (unsigned)NFA * 64u + offA, 0, 0);
+                ax[j] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+            }
+        }
         OST(45);
         if (wave == 0) {
             const bool go = wait_flags(flag_g, G, (unsigned)(step + 1), err, lane);
@@ -145,7 +160,13 @@ __device__ __forceinline__ void owner_role(const PersistArgs& a, int* go_flag, f
     #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const unsigned jb = (unsigned)min(j0 + j, n_active - 1);
-                    av[j] = load16_sc1(rA, jb * (unsigned)NFA * 64u + offA);
+                    if (!xall) av[j] = load16_sc1(rA, jb * (unsigned)NFA * 64u + offA);
+                    else if (j0 == 0) av[j] = ax[j];
+                    else {
+                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(
+                            rX, ((unsigned)step * (unsigned)G + jb) * (unsigned)NFA * 64u + offA, 0, 0);
+                        av[j] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+                    }
                     bv[j] = load16_sc1(rB, jb * (unsigned)NFB * 64u + offB);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -393,7 +414,8 @@ __device__ __forceinline__ void persist_train_body(const PersistArgs& a) {
         float bce = 0.f, kl = 0.f;
         if (active) {
             // blocked transposed copy of the X tile for the owners of the first layer's tiles (write-through, fire and forget)
-            {
+            // -- unless the whole epoch's X was transposed once in front of the launches (XT_all)
+            if (!a.XT_all) {
                 float* xt = a.XT + (long)wg * ((a.D + 15) & ~15) * 16;
                 for (int i = tid; i < FTM * a.D; i += FTHREADS) {
                     const int cc = i >> 4, r = i & 15;

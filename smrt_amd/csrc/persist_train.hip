@@ -39,6 +39,38 @@ persist_kernel_t persist_pick_kernel(const StageU* st, int n_stages) {
     return k ? k : persist_train_kernel;
 }
 
+// X of a whole epoch -> blocked transposed [step][16-row block g][rup16(D) features][16 rows], rows past a step's mini-batch and
+// features past D zero: what the compute workgroups used to publish per step as 4-byte write-through stores (X never changes
+// during a fit).  One workgroup per (step, block): the 16 x D tile goes through LDS so that both sides are coalesced.
+__global__ __launch_bounds__(256) void xt_all_kernel(const float* __restrict__ X, long ldx, long n_rows, int batch, int G, int D,
+                                                     float* __restrict__ out) {
+    __shared__ float tile[16 * 129];
+    const int NF = (D + 15) & ~15;
+    const long step = blockIdx.x / G;
+    const int g = blockIdx.x % G;
+    const long rows = min((long)batch, n_rows - step * batch);
+    const long r0 = step * batch + (long)g * 16;
+    float* dst = out + ((long)blockIdx.x * NF) * 16;
+    for (int f0 = 0; f0 < NF; f0 += 128) {
+        const int nf = min(128, NF - f0);
+        for (int i = threadIdx.x; i < 16 * nf; i += 256) {
+            const int r = i / nf, f = i - r * nf;
+            const bool in = (long)g * 16 + r < rows && f0 + f < D;
+            tile[r * 129 + f] = in ? X[(r0 + r) * ldx + f0 + f] : 0.0f;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * nf; i += 256) {
+            const int f = i >> 4, r = i & 15;
+            dst[(long)(f0 + f) * 16 + r] = tile[r * 129 + f];
+        }
+        __syncthreads();
+    }
+}
+void launch_xt_all(hipStream_t s, const float* X, long ldx, long n_rows, int batch, int G, int D, float* XT_all) {
+    const long n_steps = (n_rows + batch - 1) / batch;
+    SMRT_LAUNCH(xt_all_kernel, dim3((unsigned)(n_steps * G)), dim3(256), 0, s, X, ldx, n_rows, batch, G, D, XT_all);
+}
+
 void launch_persist_train(hipStream_t s, persist_kernel_t k, const PersistArgs& a, int n_workgroups) {
     SMRT_LAUNCH(k, dim3(n_workgroups), dim3(FTHREADS), (size_t)a.lds_total * sizeof(float), s, a);
 }

@@ -371,6 +371,8 @@ struct PersistArgs {
     float* W; float* s0; float* s1;       // flat parameter / slot buffers: read at launch start, written at launch end
     const DwTile* tiles; int total_tiles;
     float* XT; float* Zb_g;               // blocked transposed X tile copy and z (the stage records carry the other buffers)
+    const float* XT_all;                  // the WHOLE epoch's X, blocked transposed [step][16-row block][rup16(D)][16], built once per
+                                          // smrt_vae_train_epochs call (launch_xt_all); null: the compute workgroups publish XT per step
     int cap_blocks;                       // 16-row blocks the blocked transposed workspace holds
     unsigned* cnt;                        // 64 words zeroed before every launch: [0] rows published, [16] weights, [32] error
     int lds_x, s_x, lds_z, lds_e, s_z, lds_total;
@@ -382,6 +384,7 @@ struct PersistArgs {
     float lr, l2, gmin, gmax;
     unsigned long long* dbg;              // diagnostic builds only (-DSMRT_STAMPS): phase time stamps, step 4
 };
+void launch_xt_all(hipStream_t s, const float* X, long ldx, long n_rows, int batch, int G, int D, float* XT_all);
 typedef void (*persist_kernel_t)(const PersistArgs);
 persist_kernel_t persist_pick_kernel(const StageU* stages, int n_stages);   // the instantiation written out for this table, else the generic kernel
 void launch_persist_train(hipStream_t s, persist_kernel_t k, const PersistArgs& a, int n_workgroups);
