@@ -110,6 +110,7 @@ struct smrt_vae {
     DwTile* tile_tab = nullptr;      // per-tile records of the fused dW + optimizer kernel
     StageU* stage_u = nullptr;       // the persistent kernel's stage records, decoded (ensure_train)
     int n_stage_u = 0;
+    fused_kernel_t fkernel = nullptr;     // ... and the two-kernel step's forward / backward launch
     persist_kernel_t pkernel = nullptr;   // the persistent kernel for this net: a sequence-specialised instantiation or the generic one
     DwRec* dwrec = nullptr;          // small-batch fused weight-gradient + update launch: 32x32 tile records, then 64x64 ones
     int n_rec32 = 0;
@@ -264,7 +265,7 @@ static void plan_fused(smrt_vae* h) {
     const bool want = e ? std::atoi(e) != 0 : true;
     const int bytes = off * (int)sizeof(float);
     h->fused = want && bytes <= 150 * 1024 && !h->ae;
-    if (h->fused && bytes > 48 * 1024 && fused_set_max_lds(bytes) != 0) { (void)hipGetLastError(); h->fused = false; }
+    if (h->fused && bytes > 48 * 1024 && fused_set_max_lds(fused_pick_kernel(nullptr, 0), bytes) != 0) { (void)hipGetLastError(); h->fused = false; }
     const char* pe = std::getenv("SMRT_HIP_PERSIST");
     h->persist_ok = h->fused && (pe ? std::atoi(pe) != 0 : true) && h->cfg.dropout_keep >= 1.0f;
     if (h->persist_ok && bytes > 48 * 1024 && persist_set_max_lds(persist_pick_kernel(nullptr, 0), bytes) != 0) { (void)hipGetLastError(); h->persist_ok = false; }
@@ -512,6 +513,12 @@ static int ensure_train(smrt_vae* h, int rows) {
         }
         su[ns] = su[ns - 1];
         h->n_stage_u = ns;
+        h->fkernel = fused_pick_kernel(su, ns);
+        if (h->fkernel != fused_pick_kernel(nullptr, 0) && h->fplan.lds_total * (int)sizeof(float) > 48 * 1024 &&
+            fused_set_max_lds(h->fkernel, h->fplan.lds_total * (int)sizeof(float)) != 0) {
+            (void)hipGetLastError();
+            h->fkernel = fused_pick_kernel(nullptr, 0);
+        }
         h->pkernel = persist_pick_kernel(su, ns);
         if (h->pkernel != persist_pick_kernel(nullptr, 0) && h->fplan.lds_total * (int)sizeof(float) > 48 * 1024 &&
             persist_set_max_lds(h->pkernel, h->fplan.lds_total * (int)sizeof(float)) != 0) {
@@ -694,7 +701,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             h->img_valid = true;
         }
         FusedArgs f = h->fplan;
-        f.n_stages = build_stages(h, f, f.stages);
+        f.n_stages = h->n_stage_u; f.stage_u = h->stage_u;
         f.X = X; f.ldx = ldx; f.rows = rows; f.eps_in = eps_in; f.Wimg = h->Wimg; f.Zb_g = h->ZT;
         f.XT = h->XT;
         f.seed = h->cfg.seed; f.st = h->st; f.row0_global = row0_global;
@@ -704,7 +711,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         if (!dbgbuf) { (void)hipMalloc((void**)&dbgbuf, 64 * 8); (void)hipMemset(dbgbuf, 0, 64 * 8); }
         f.dbg = dbgbuf;
 #endif
-        { ProfScope ps(h, PK_FUSED); launch_fused_fwd_bwd(s, f); } ++launches;
+        { ProfScope ps(h, PK_FUSED); launch_fused_fwd_bwd(s, h->fkernel ? h->fkernel : fused_pick_kernel(nullptr, 0), f); } ++launches;
 #ifdef SMRT_STAMPS
         {   // diagnostic build: print block 0's phase durations of the 4th launch (wall_clock64 = 100 MHz)
             (void)hipStreamSynchronize(s);

@@ -73,8 +73,6 @@ __device__ __forceinline__ bool wait_flags(unsigned* f, int n, unsigned target, 
     }
 }
 
-typedef const __attribute__((address_space(4))) i32x16 stage_rec_t;      // constant address space: uniform index -> s_load_dwordx16
-
 constexpr int OWNER_TILES = 4;          // tiles (= working waves) per owner workgroup
 
 #ifdef SMRT_STAMPS
@@ -246,56 +244,6 @@ __device__ __forceinline__ void owner_role(const PersistArgs& a, int* go_flag, f
         }
 }
 
-// ---- the stage sequence of one mini-batch, two forms.
-// SeqGeneric: a loop over the records; each stage runs through exec_stage_variant's switch.
-// SeqVae1<DB, HB, ZB, Z2B>: the seven stages of a VAE with ONE hidden layer and sigmoid activations whose padded widths are
-//   16 DB (features), 16 HB (hidden), 16 ZB (latent), 16 Z2B (both heads), written out with each stage's structure-specialised
-//   body -- no loop, no switch.  Measured on the bench net (64-128-(16,16)-128-64), same bodies: 15.2 us per mini-batch through
-//   the loop + switch, 13.45 us written out (the generic body written out: no gain; it is the combination that pays).
-//   The host picks the instantiation from the stage table itself (persist_seq_kernel), else the generic kernel.
-struct SeqGeneric {
-    template <class Stamp>
-    static __device__ __forceinline__ void run(const PersistArgs& a, stage_rec_t* stage_tab, StageCtx& sx, float& bce, float& kl, Stamp stamp) {
-        i32x16 u = stage_tab[0];
-#pragma unroll 1
-        for (int st = 0; st < a.n_stages; ++st) {
-            const StageDec cur = decode_stage_u(u, sx);
-            const int out_off = u[8], s_out = u[9];
-            const int kind = exec_stage_variant<2>((u[6] >> 24) & 255, cur, sx, bce);
-            // the next stage's record is requested in front of this stage's barrier, behind its last LDS access (a scalar
-            // load in flight would turn the fragment reads' counted waits into waits for everything)
-            __builtin_amdgcn_sched_barrier(0);
-            u = stage_tab[st + 1];
-            __builtin_amdgcn_sched_barrier(0);
-            lds_barrier();
-            if (kind == FK_FWD_HEADS) reparam_after_heads<2>(make_int4(out_off, s_out, 0, 0), sx, kl);
-            stamp(st);
-        }
-    }
-};
-template <int DB, int HB, int ZB, int Z2B>
-struct SeqVae1 {
-    template <int ST, int K_, int NB_, int NT_, class Stamp>
-    static __device__ __forceinline__ void stage(stage_rec_t* stage_tab, StageCtx& sx, float& bce, float& kl, Stamp stamp) {
-        const i32x16 u = stage_tab[ST];
-        const StageDec d = decode_stage_u(u, sx);
-        exec_stage<2, K_, NB_, ACT_SIGMOID, NT_>(d, sx, bce);
-        lds_barrier();
-        if constexpr (K_ == FK_FWD_HEADS) reparam_after_heads<2>(make_int4(u[8], u[9], 0, 0), sx, kl);
-        stamp(ST);
-    }
-    template <class Stamp>
-    static __device__ __forceinline__ void run(const PersistArgs&, stage_rec_t* stage_tab, StageCtx& sx, float& bce, float& kl, Stamp stamp) {
-        stage<0, FK_FWD_ACT, DB, HB>(stage_tab, sx, bce, kl, stamp);
-        stage<1, FK_FWD_HEADS, HB, Z2B>(stage_tab, sx, bce, kl, stamp);
-        stage<2, FK_FWD_ACT, ZB, HB>(stage_tab, sx, bce, kl, stamp);
-        stage<3, FK_FWD_BCE, HB, DB>(stage_tab, sx, bce, kl, stamp);
-        stage<4, FK_BWD_ACT, DB, HB>(stage_tab, sx, bce, kl, stamp);
-        stage<5, FK_BWD_LATENT, HB, ZB>(stage_tab, sx, bce, kl, stamp);
-        stage<6, FK_BWD_ACT, Z2B, HB>(stage_tab, sx, bce, kl, stamp);
-    }
-};
-
 template <class Seq>
 __device__ __forceinline__ void persist_train_body(const PersistArgs& a) {
     extern __shared__ __align__(16) float lds[];
@@ -428,7 +376,7 @@ __device__ __forceinline__ void persist_train_body(const PersistArgs& a) {
 #ifdef SMRT_STAMPS
             sx.sdbg = nullptr;
 #endif
-            Seq::run(a, stage_tab, sx, bce, kl, [&](int st) { (void)st; PST(4 + st); });
+            Seq::run(a.n_stages, stage_tab, sx, bce, kl, [&](int st) { (void)st; PST(4 + st); });
         }
         PST(40);
         // the X tile is free now: request the next step's while the update is under way

@@ -6,30 +6,32 @@
 
 namespace smrt {
 
-__global__ __launch_bounds__(FTHREADS) void persist_train_kernel(const PersistArgs a) { persist_train_body<SeqGeneric>(a); }
+__global__ __launch_bounds__(FTHREADS) void persist_train_kernel(const PersistArgs a) { persist_train_body<SeqGeneric<2>>(a); }
 
 // persist_seq.hip, compiled once per hidden width (Makefile): nullptr when the instantiation does not exist
 persist_kernel_t persist_seq_kernel_h2(int db, int zb, int z2b);
 persist_kernel_t persist_seq_kernel_h4(int db, int zb, int z2b);
 persist_kernel_t persist_seq_kernel_h8(int db, int zb, int z2b);
 
-// The instantiation written out for this stage table, if there is one: a VAE with one hidden layer, sigmoid everywhere, every
-// padded width 16 / 32 / 64 / 128 -- checked against the records themselves, so a table of any other shape gets the generic kernel.
-persist_kernel_t persist_pick_kernel(const StageU* st, int n_stages) {
+// Whether this stage table is the pattern the written-out kernels exist for: a VAE with one hidden layer, sigmoid everywhere,
+// every padded width 16 / 32 / 64 / 128 -- checked against the records themselves, so a table of any other shape gets the
+// generic kernels.
+bool seq_vae1_shape(const StageU* st, int n_stages, int& db, int& hb, int& zb, int& z2b) {
     const char* e = std::getenv("SMRT_HIP_PERSIST_SEQ");             // (read per call: tests compare the two builds)
-    if ((e && std::atoi(e) == 0) || n_stages != 7 || !st) return persist_train_kernel;
-    auto kind = [&](int i) { return st[i].packed & 255; };
-    auto act = [&](int i) { return (st[i].packed >> 8) & 255; };
+    if ((e && std::atoi(e) == 0) || n_stages != 7 || !st) return false;
     auto nb = [&](int i) { return st[i].nb_all; };
     auto nt = [&](int i) { return st[i].N16 >> 4; };
     static const int want[7] = {FK_FWD_ACT, FK_FWD_HEADS, FK_FWD_ACT, FK_FWD_BCE, FK_BWD_ACT, FK_BWD_LATENT, FK_BWD_ACT};
     for (int i = 0; i < 7; ++i)
-        if (kind(i) != want[i] || act(i) != STAGE_ACT_SIGMOID ||
-            st[i].nn != (want[i] >= FK_BWD_ACT ? 16 * nb(i) : st[i].N16) + 1) return persist_train_kernel;
-    const int db = nb(0), hb = nt(0), zb = nb(2), z2b = nt(1);
-    const bool same = nb(1) == hb && nt(2) == hb && nb(3) == hb && nt(3) == db && nb(4) == db && nt(4) == hb && nb(5) == hb &&
-                      nt(5) == zb && nb(6) == z2b && nt(6) == hb;
-    if (!same) return persist_train_kernel;
+        if ((st[i].packed & 255) != want[i] || ((st[i].packed >> 8) & 255) != STAGE_ACT_SIGMOID ||
+            st[i].nn != (want[i] >= FK_BWD_ACT ? 16 * nb(i) : st[i].N16) + 1) return false;
+    db = nb(0); hb = nt(0); zb = nb(2); z2b = nt(1);
+    return nb(1) == hb && nt(2) == hb && nb(3) == hb && nt(3) == db && nb(4) == db && nt(4) == hb && nb(5) == hb &&
+           nt(5) == zb && nb(6) == z2b && nt(6) == hb;
+}
+persist_kernel_t persist_pick_kernel(const StageU* st, int n_stages) {
+    int db, hb, zb, z2b;
+    if (!seq_vae1_shape(st, n_stages, db, hb, zb, z2b)) return persist_train_kernel;
 #ifdef SMRT_SEQ_ONLY8              // (diagnostic and A/B builds carry the 128-wide instantiations only)
     persist_kernel_t k = hb == 8 ? persist_seq_kernel_h8(db, zb, z2b) : nullptr;
 #else

@@ -312,7 +312,7 @@ struct StageU {
 };
 static_assert(sizeof(StageU) == 64, "StageU is read by one s_load_dwordx16");
 struct FusedArgs {
-    FusedStage stages[2 * MAX_LAYERS];
+    const StageU* stage_u;                // n_stages + 1 decoded records in device memory (as PersistArgs)
     int n_stages;
     int NL, L, Z, D;
     const float* X; long ldx; int rows;
@@ -327,7 +327,12 @@ struct FusedArgs {
     float* bce_p; float* kl_p;
     unsigned long long* dbg;      // diagnostic builds only (-DSMRT_STAMPS): phase time stamps of block 0
 };
-void launch_fused_fwd_bwd(hipStream_t s, const FusedArgs& a);
+typedef void (*fused_kernel_t)(const FusedArgs);
+fused_kernel_t fused_pick_kernel(const StageU* stages, int n_stages);      // the instantiation written out for this table, else the generic kernel
+void launch_fused_fwd_bwd(hipStream_t s, fused_kernel_t k, const FusedArgs& a);
+// Whether a stage table is a one-hidden-layer sigmoid VAE of the padded widths the written-out kernels exist for (in 16-wide
+// blocks: features db, hidden hb, latent zb, both heads z2b); SMRT_HIP_PERSIST_SEQ=0 answers no.
+bool seq_vae1_shape(const StageU* st, int n_stages, int& db, int& hb, int& zb, int& z2b);
 
 // dW + optimizer fused (fused_small.hip)
 struct DwTile {            // one 16x16 tile of one layer's [X | 1]^T . dPre: 64 bytes, read by one scalar load
@@ -412,7 +417,7 @@ struct InferArgs {
 };
 int  launch_fused_infer(hipStream_t s, const InferArgs& a);
 int  dw_opt_blocks(int total_tiles);
-int  fused_set_max_lds(int bytes);
+int  fused_set_max_lds(fused_kernel_t k, int bytes);
 void launch_build_image(hipStream_t s, const float* Wflat, const int* tab, float* img, int n_f4);
 
 constexpr int SMALL_M_MAX = 512;    // mini-batches up to this many rows take the register-fed small-tile kernels (small_gemm.hip)
