@@ -565,6 +565,8 @@ __device__ __forceinline__ void optimizer_body(const OptArgs& a) {
     __shared__ float red[4];
     const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     float l2acc = 0.f;
+    const float b1pow = a.st->b1pow, b2pow = a.st->b2pow;      // (requested with everything else; block 0 advances them below)
+    __builtin_amdgcn_sched_barrier(0);
     if (a.advance && blockIdx.x == 0 && threadIdx.x == 0) {
         // every earlier kernel of the step has read the step scalars (stream order) and no block of this one does
         a.st->step += 1;
@@ -595,7 +597,16 @@ __device__ __forceinline__ void optimizer_body(const OptArgs& a) {
             seg_l2 = in ? a.seg[j].l2 : seg_l2;
         }
         const bool is_w = (i0 - seg_start) < seg_wcount;
-        for (int s = 1; s < a.splits; ++s) {
+        // the other slabs, four requests at a time (summed in slab order: the same bits as one by one)
+        int s = 1;
+        for (; s + 4 <= a.splits; s += 4) {
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const float4*>(a.G + (long)(s + u) * a.slab_stride + i0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { g.x += t[u].x; g.y += t[u].y; g.z += t[u].z; g.w += t[u].w; }
+        }
+        for (; s < a.splits; ++s) {
             const float4 t = *reinterpret_cast<const float4*>(a.G + (long)s * a.slab_stride + i0);
             g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
         }
@@ -615,7 +626,7 @@ __device__ __forceinline__ void optimizer_body(const OptArgs& a) {
         }
         if (a.grad_out) *reinterpret_cast<float4*>(a.grad_out + i0) = make_float4(gv[0], gv[1], gv[2], gv[3]);
         float alpha = 0.f;
-        if (a.opt == 2) alpha = a.lr * sqrtf(1.0f - a.st->b2pow) / (1.0f - a.st->b1pow);
+        if (a.opt == 2) alpha = a.lr * sqrtf(1.0f - b2pow) / (1.0f - b1pow);
         const bool has_s0 = a.opt != 0 && a.opt != 5;
         const bool has_s1 = a.opt == 1 || a.opt == 2 || a.opt == 4;
         float s0v[4] = {s0.x, s0.y, s0.z, s0.w}, s1v[4] = {s1.x, s1.y, s1.z, s1.w};
