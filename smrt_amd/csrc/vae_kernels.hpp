@@ -415,6 +415,7 @@ struct InferArgs {
     uint64_t gen_seed, gen_elem0; float gen_loc, gen_scale;
     unsigned long long* dbg;              // diagnostic builds only (-DSMRT_STAMPS)
 };
+typedef void (*infer_kernel_t)(const InferArgs);
 int  launch_fused_infer(hipStream_t s, const InferArgs& a);
 int  dw_opt_blocks(int total_tiles);
 int  fused_set_max_lds(fused_kernel_t k, int bytes);

@@ -413,6 +413,32 @@ def test_generate_across_z_chunks_is_position_independent():
     h.close()
 
 
+def test_inference_chains_written_out_equal_the_generic_launch(monkeypatch, kernel_path):
+    """infer_seq.hip: encode / decode / generate of one-hidden-layer nets whose padded widths are 16 / 32 / 64 / 128 run a
+    two-layer chain written out per shape (no loop over stage records, no switch over tile counts per 16-row block).
+    Same arithmetic in the same order as the generic launch (SMRT_HIP_INFER_SEQ=0): bit-identical, ragged widths and a
+    ragged row count included; nets outside the table (two hidden layers, 48-wide) take the generic launch either way."""
+    if kernel_path != "fused":
+        pytest.skip("the one-launch inference kernel belongs to the LDS-resident (fused) path")
+    import torch
+    n = 5003
+    for D, hidden, Z in ((64, [128], 16), (16, [32], 8), (29, [60], 12), (128, [64], 32), (100, [64], 5), (40, [20, 12], 4)):
+        rs = np.random.RandomState(D + Z)
+        h = _handle(D, hidden, Z, seed=5, max_batch=64)
+        h.set_params((rs.normal(size=h.n_params) * 0.2).astype(np.float32))
+        X, Zs = rs.uniform(0, 1, size=(n, D)), rs.normal(size=(n, Z))
+        outs = []
+        for seq in ("1", "0"):
+            monkeypatch.setenv("SMRT_HIP_INFER_SEQ", seq)
+            mu, ls = h.encode(X)
+            outs.append((mu, ls, h.decode(Zs), h.generate(n, philox_offset=8)))
+        monkeypatch.delenv("SMRT_HIP_INFER_SEQ")
+        for a, b, what in zip(outs[0], outs[1], ("mu", "log_sigma", "decode", "generate")):
+            np.testing.assert_array_equal(a, b, err_msg="%s of %d-%s-%d" % (what, D, hidden, Z))
+        assert np.isfinite(outs[0][2]).all()
+        h.close()
+
+
 # ---------------------------------------------------------------------------------------- persistent whole-epoch kernel
 def _persist_pair(monkeypatch, D, hidden, Z, act, opt, max_batch, rs, lr=0.01, l2=1e-4, clip=True, seed=11):
     """(oracle, handle on the persistent path, handle on the two-kernel path) with the same injected weights."""
