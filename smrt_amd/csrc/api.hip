@@ -1181,7 +1181,6 @@ int smrt_vae_set_dropout_masks(smrt_vae* h, const float* host_flat, int64_t n) {
 static int ensure_cost(smrt_vae* h, long n) {
     if (n > h->cost_pin_cap) {
         if (h->cost_pin) (void)hipHostFree(h->cost_pin);
-    if (h->xt_all) (void)hipFree(h->xt_all);
         if (h->err_pin) (void)hipHostFree(h->err_pin);
         h->cost_pin = nullptr; h->err_pin = nullptr; h->cost_pin_cap = 0;
         HIPC(hipHostMalloc((void**)&h->cost_pin, sizeof(float) * n, hipHostMallocDefault));

@@ -579,6 +579,27 @@ def test_every_written_out_instantiation_equals_the_generic_kernel(monkeypatch, 
     assert ran >= 30, ran
 
 
+def test_persistent_calls_of_growing_length_and_other_data(monkeypatch, kernel_path):
+    """Workspace that outlives a call (the pinned per-epoch cost mirror, the once-per-call transposed copy of X): a second call
+    with MORE epochs (the mirror is re-allocated), then one on a LARGER X (the copy is re-allocated), then a smaller one, each
+    against the two-kernel path.  (Round 3: the mirror's growth path freed the transposed copy still in use.)"""
+    if kernel_path != "fused":
+        pytest.skip("the persistent kernel belongs to the LDS-resident (fused) path")
+    rs = np.random.RandomState(77)
+    D, hidden, Z, B = 64, [128], 16, 128
+    o, hp, h2 = _persist_pair(monkeypatch, D, hidden, Z, "sigmoid", "rms_prop", B, rs)
+    for n, epochs in ((300, 2), (300, 7), (1500, 3), (200, 9)):
+        X = rs.uniform(0, 1, size=(n, D))
+        cp, _ = hp.train_epochs(X, B, epochs)
+        c2, _ = h2.train_epochs(X, B, epochs)
+        assert hp.last_epoch_launches == 2 and len(cp) == epochs
+        np.testing.assert_allclose(cp, c2, rtol=1e-4)
+    _close(hp.get_params(), h2.get_params(), "after four calls", rtol=1e-4)
+    import torch
+    assert bool(torch.isfinite(torch.zeros(4, device="cuda")).all())          # no HIP error left behind for the next caller
+    hp.close(); h2.close()
+
+
 def test_persistent_early_stopping_and_ineligible_nets(monkeypatch, kernel_path):
     """Early stopping reads the cost after every persistent launch; dropout nets keep the two-kernel step."""
     if kernel_path != "fused":
