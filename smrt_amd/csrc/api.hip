@@ -82,6 +82,10 @@ struct smrt_vae {
     int n_l2 = 0, l2_cap = 0;            // l2 partials of the optimizer sweep; capacity of l2_p
     float* cost_dev = nullptr; long cost_cap = 0;
     float* cost_pin = nullptr; long cost_pin_cap = 0;
+    unsigned long long* time_pin = nullptr;   // epoch ring: time stamps (cost_pin_cap + 1 of them; FinalizeArgs::ring_time)
+    unsigned* ep_ctr = nullptr;          // epoch ring: index of the running epoch (device)
+    bool ring_on = false;                // steps that close an epoch write the ring (set for the duration of a train_epochs call)
+    bool g_ring = false;                 // ... and the cached epoch graph was built that way
     unsigned* err_pin = nullptr;         // per-epoch copies of the persistent kernel's error word (same capacity as cost_pin)
 
     long icap = 0, izcap = 0;
@@ -615,7 +619,9 @@ static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_r
     // (192) is STICKY across the launches of one smrt_vae_train_epochs call: it is cleared once, at the start of the call,
     // every workgroup reads it in its prologue and leaves at once when it is set -- an epoch that follows a timed-out one
     // must not train on the half-updated image twin, and the host must still see the error after the last epoch.
-    if (hipMemsetAsync(h->pcnt, 0, 192 * sizeof(unsigned), s) != hipSuccess) return -1;
+    // (With the epoch ring the launch that closes the previous epoch has cleared them, and the call's first launch follows
+    // train_epochs' own clear of all 256 words.)
+    if (!h->ring_on && hipMemsetAsync(h->pcnt, 0, 192 * sizeof(unsigned), s) != hipSuccess) return -1;
     // test hook (SMRT_HIP_PERSIST_FAULT_EPOCH): raise the error word in front of this launch, as a peer's time-out would
     if (inject_fault && hipMemsetAsync(h->pcnt + 192, 1, sizeof(unsigned), s) != hipSuccess) return -1;
 #ifdef SMRT_STAMPS
@@ -658,6 +664,10 @@ static int enqueue_persist_epoch(smrt_vae* h, const float* X, long ldx, long n_r
     fa.bce = h->bce_p; fa.n_bce = (int)((rows_last + 15) / 16); fa.kl = h->kl_p; fa.n_kl = fa.n_bce;
     fa.l2p = h->l2_p; fa.n_l2 = n_owner; fa.inv_batch = 1.0f / (float)rows_last; fa.l2 = a.l2;
     fa.cost_out = cost_slot; fa.st = h->st; fa.advance = 0;
+    if (h->ring_on) {
+        fa.ring_cost = h->cost_pin; fa.ring_time = h->time_pin; fa.ring_ctr = h->ep_ctr;
+        fa.err_src = h->pcnt + 192; fa.ring_err = h->err_pin; fa.zero192 = h->pcnt;
+    }
     { ProfScope ps(h, PK_FINAL); launch_finalize(s, fa); }
     return 2;
 }
@@ -683,6 +693,10 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         { ProfScope ps(h, PK_DROPOUT); launch_dropout(s, d); } ++launches;
         Wuse = h->Wd;
     }
+    // the launch that closes an epoch of a train_epochs call reports cost and time through the epoch ring (FinalizeArgs)
+    auto ring = [&](FinalizeArgs& f) {
+        if (h->ring_on && o.cost_slot == h->cost_dev) { f.ring_cost = h->cost_pin; f.ring_time = h->time_pin; f.ring_ctr = h->ep_ctr; }
+    };
     const int HL = h->hl;               // fused latent heads layer (-2 for the plain auto-encoder: never matches)
     auto in_of = [&](int l) -> const float* { return l == 0 ? X : (l == HL + 1 ? h->Zb : h->out[l - 1]); };
     auto ldin_of = [&](int l) -> long { return l == 0 ? ldx : (l == HL + 1 ? (long)rup4(Z) : (long)h->lay[l - 1].ld); };
@@ -862,6 +876,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
             f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p;
             f.n_l2 = dw_opt_blocks(tb); f.inv_batch = inv_batch; f.l2 = d.l2; f.cost_out = o.cost_slot;
             f.st = h->st; f.advance = 0;
+            ring(f);
             { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
         }
         h->last_epoch_launches = launches;
@@ -919,6 +934,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
                 f.inv_batch = h->ae ? inv_batch / (float)h->D : inv_batch; f.l2 = d.l2;
                 f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
                 f.st = h->st; f.advance = d.advance ? 0 : 1;
+                ring(f);
                 { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
             }
             h->last_epoch_launches = launches;
@@ -968,6 +984,7 @@ static int enqueue_step(smrt_vae* h, const float* X, long ldx, int rows, float i
         f.bce = h->bce_p; f.n_bce = n_bce; f.kl = h->kl_p; f.n_kl = n_kl; f.l2p = h->l2_p; f.n_l2 = h->n_l2;
         f.inv_batch = h->ae ? inv_batch / (float)h->D : inv_batch; f.l2 = p.l2; f.cost_out = o.cost_slot ? o.cost_slot : h->cost_dev + 1;
         f.st = h->st; f.advance = p.advance ? 0 : 1;
+        ring(f);
         { ProfScope ps(h, PK_FINAL); launch_finalize(s, f); } ++launches;
     }
     h->last_epoch_launches = launches;
@@ -1030,6 +1047,7 @@ int smrt_vae_create(const smrt_vae_cfg* cfg, int device, smrt_vae** out) {
             carve(a, &h->st, (size_t)1);
             carve(a, &h->ticket, (size_t)4);
             carve(a, &h->pcnt, (size_t)256);
+            carve(a, &h->ep_ctr, (size_t)4);
             carve(a, &h->cost_dev, (size_t)4);
             carve(a, &h->l2_p, (size_t)h->l2_cap);     // (>= persist_owner_workgroups, >= the 32x32 tiles of small_dw_opt)
             carve(a, &h->stage_tab, h->fused ? (size_t)h->P_int / 4 : 0);
@@ -1072,6 +1090,7 @@ void smrt_vae_destroy(smrt_vae* h) {
     float* ibufs[] = {h->ibuf[0], h->ibuf[1], h->izb};
     for (float* b : ibufs) if (b) (void)hipFree(b);
     if (h->cost_pin) (void)hipHostFree(h->cost_pin);
+    if (h->time_pin) (void)hipHostFree(h->time_pin);
     if (h->xt_all) (void)hipFree(h->xt_all);
     if (h->err_pin) (void)hipHostFree(h->err_pin);
     for (hipEvent_t e : h->events) (void)hipEventDestroy(e);
@@ -1182,8 +1201,11 @@ static int ensure_cost(smrt_vae* h, long n) {
     if (n > h->cost_pin_cap) {
         if (h->cost_pin) (void)hipHostFree(h->cost_pin);
         if (h->err_pin) (void)hipHostFree(h->err_pin);
-        h->cost_pin = nullptr; h->err_pin = nullptr; h->cost_pin_cap = 0;
+        if (h->time_pin) (void)hipHostFree(h->time_pin);
+        h->cost_pin = nullptr; h->err_pin = nullptr; h->time_pin = nullptr; h->cost_pin_cap = 0;
+        drop_graph(h);                                   // (a cached epoch graph writes the ring through the old pointers)
         HIPC(hipHostMalloc((void**)&h->cost_pin, sizeof(float) * n, hipHostMallocDefault));
+        HIPC(hipHostMalloc((void**)&h->time_pin, sizeof(unsigned long long) * (n + 1), hipHostMallocDefault));
         HIPC(hipHostMalloc((void**)&h->err_pin, sizeof(unsigned) * n, hipHostMallocDefault));
         h->cost_pin_cap = n;
     }
@@ -1232,10 +1254,12 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     }
     std::vector<float> ep_ms((size_t)std::max(n_epochs, 1), 0.f);
     int harvested = 0;
+    bool ring = false;                              // the epoch ring instead of an event pair + a copy per epoch (set below)
     auto harvest = [&](int upto) {                  // epochs [harvested, upto) have completed
         for (; harvested < upto; ++harvested) {
             const int k = harvested % EV_RING;
-            (void)hipEventElapsedTime(&ep_ms[harvested], h->events[2 * k], h->events[2 * k + 1]);
+            if (ring) ep_ms[harvested] = (float)((double)(h->time_pin[harvested + 1] - h->time_pin[harvested]) * 1e-5);   // 100 MHz
+            else (void)hipEventElapsedTime(&ep_ms[harvested], h->events[2 * k], h->events[2 * k + 1]);
         }
     };
     if (epochs_done) *epochs_done = 0;
@@ -1260,7 +1284,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     const int fault_epoch = (fe_env && *fe_env) ? std::atoi(fe_env) : -1;
     const char* nf_env = std::getenv("SMRT_HIP_PERSIST_NO_FALLBACK");
     const bool no_fallback = nf_env && std::atoi(nf_env) != 0;
-    if (PG) HIPC(hipMemsetAsync(h->pcnt + 192, 0, 64 * sizeof(unsigned), h->stream));      // the sticky error word: once per call
+    if (PG) HIPC(hipMemsetAsync(h->pcnt, 0, 256 * sizeof(unsigned), h->stream));   // producer flags + the sticky error word: once per call
     // X does not change during the call: its blocked-transposed form (the first layer's weight-gradient operand) is built once,
     // in front of the epochs, instead of being published by the compute workgroups every step -- when it fits the cap
     // (SMRT_HIP_XT_ALL_MB, default 1024; 0 keeps the per-step form)
@@ -1281,6 +1305,16 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
         }
     }
     int cur_epoch = 0;
+    // Without the persistent kernel an epoch is a graph of a few launches (two mini-batches of the reference's own 500-row
+    // example: 13 nodes, 115 us): an event pair and a 4-byte copy per epoch around it were 12 of its 134 us.  The launch that
+    // closes the epoch writes cost and time into pinned memory itself (FinalizeArgs::ring_*); SMRT_HIP_EPOCH_RING=0 keeps
+    // the events and copies.  A persistent epoch (one launch + the cost launch) gets rid of five more stream operations
+    // that way: the flag clear in front of every launch, two event records, the cost copy and the error-word copy.
+    const char* ring_e = std::getenv("SMRT_HIP_EPOCH_RING");          // (read per call: tests switch it)
+    ring = !(ring_e && std::atoi(ring_e) == 0);
+    struct RingOff { smrt_vae* h; ~RingOff() { h->ring_on = false; } } ring_off{h};
+    h->ring_on = ring;
+    if (ring) launch_ring_start(h->stream, h->time_pin, h->ep_ctr, 0u);
 
     // Enqueue one epoch (every contiguous batch, ragged tail last: sklearn gen_batches, base.py:198-199).
     // The cost of the LAST batch lands in `slot` (base.py:222); other steps write a scratch slot.
@@ -1307,7 +1341,8 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     // lives in device memory, so only the cost slot differs -> the graph writes slot 0 and a copy node moves it.
     bool graphed = false;
     if (h->use_graph && !PG && !h->prof && n_epochs > 1 && h->stream == h->own_stream) {
-        const bool hit = h->gexec && h->g_X == X_dev && h->g_ldx == ldx && h->g_n == n_rows && h->g_batch == batch_size;
+        const bool hit = h->gexec && h->g_X == X_dev && h->g_ldx == ldx && h->g_n == n_rows && h->g_batch == batch_size &&
+                         h->g_ring == ring;
         if (hit) { graphed = true; h->last_epoch_launches = h->g_launches; }
         else {
             drop_graph(h);
@@ -1323,7 +1358,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
                     hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0) == hipSuccess) {
                     graphed = true;
                     h->g_X = X_dev; h->g_ldx = ldx; h->g_n = n_rows; h->g_batch = batch_size;
-                    h->g_launches = h->last_epoch_launches;
+                    h->g_launches = h->last_epoch_launches; h->g_ring = ring;
                 } else {
                     (void)hipGetLastError(); drop_graph(h);
                     if (rc) return rc;
@@ -1333,12 +1368,17 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
     }
     int done = 0; float last_cost = 0.f; bool have_last = false; int rc = 0;
     auto run_epoch = [&](int ep) -> int {
-        if (ep - harvested >= EV_RING) {            // the ring is full: wait for what is queued, read its times
+        cur_epoch = ep;
+        if (ring) {
+            if (graphed) HIPC(hipGraphLaunch(h->gexec, h->stream));
+            else TRY(enqueue_epoch(h->cost_dev));
+            return 0;
+        }
+        if (ep - harvested >= EV_RING) {            // the ring of events is full: wait for what is queued, read its times
             HIPC(hipStreamSynchronize(h->stream));
             harvest(ep);
         }
         const int k = ep % EV_RING;
-        cur_epoch = ep;
         HIPC(hipEventRecord(h->events[2 * k], h->stream));
         if (graphed) HIPC(hipGraphLaunch(h->gexec, h->stream));
         else TRY(enqueue_epoch(h->cost_dev));
@@ -1357,11 +1397,12 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
         for (int ep = from; ep < upto; ++ep) if (h->err_pin[ep] != 0u) return ep;
         return -1;
     };
-    auto leave_persistent = [&]() -> int {
+    auto leave_persistent = [&](int from_epoch) -> int {
         PG = 0; release.drop();
         h->img_valid = false;
         ensure_image(h);
         HIPC(hipMemsetAsync(h->pcnt + 192, 0, 64 * sizeof(unsigned), h->stream));
+        if (ring) launch_ring_start(h->stream, h->time_pin, h->ep_ctr, (unsigned)from_epoch);   // the ring goes on at that epoch
         return 0;
     };
     const char* give_up = "smrt_vae_train_epochs: the persistent training kernel gave up waiting for a peer workgroup (2 s) and "
@@ -1378,7 +1419,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
             if (no_fallback) { h->steps += (int64_t)bad * nb; h->img_valid = false; return fail(-6, give_up); }
             harvest(bad);
             harvested = std::min(harvested, bad);          // the epochs from `bad` on are timed again
-            TRY(leave_persistent());
+            TRY(leave_persistent(bad));
             ep0 = bad;
         }
         done = n_epochs;
@@ -1391,7 +1432,7 @@ int smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t 
             if (first_failed(ep, ep + 1) >= 0) {
                 if (no_fallback) { h->steps += (int64_t)ep * nb; h->img_valid = false; return fail(-6, give_up); }
                 harvest(ep);
-                TRY(leave_persistent());
+                TRY(leave_persistent(ep));
                 rc = run_epoch(ep);
                 if (rc) return rc;
                 e = hipStreamSynchronize(h->stream);
@@ -1439,6 +1480,15 @@ int smrt_vae_train_epochs_multi(smrt_vae** hs, int32_t n_handles, const float* c
         HIPC(hipStreamSynchronize(hs[k]->stream));
         TRY(ensure_train(hs[k], (int)std::min<int64_t>(batch_size, n_rows[k])));
         TRY(ensure_cost(hs[k], n_epochs + 1));
+    }
+    // every handle reports its epochs' costs and end times through its own epoch ring (FinalizeArgs::ring_*): no copy per
+    // handle and epoch, no event pairs (SMRT_HIP_EPOCH_RING=0 keeps them)
+    const char* ring_e = std::getenv("SMRT_HIP_EPOCH_RING");
+    const bool ring = !(ring_e && std::atoi(ring_e) == 0);
+    struct RingOff { smrt_vae** hs; int n; ~RingOff() { for (int k = 0; k < n; ++k) hs[k]->ring_on = false; } } ring_off{hs, n_handles};
+    for (int k = 0; k < n_handles; ++k) {
+        hs[k]->ring_on = ring;
+        if (ring) launch_ring_start(stream, hs[k]->time_pin, hs[k]->ep_ctr, 0u);
     }
     // 1. record every handle's epoch, step by step (nothing is launched)
     std::vector<std::vector<std::vector<RecordedLaunch>>> rec(n_handles);       // [handle][step][launch]
@@ -1526,10 +1576,15 @@ int smrt_vae_train_epochs_multi(smrt_vae** hs, int32_t n_handles, const float* c
         graphed = e == hipSuccess && nodes > 0 && hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
         if (!graphed) (void)hipGetLastError();
     }
-    std::vector<hipEvent_t> ev(2 * (size_t)n_epochs, nullptr);
+    std::vector<hipEvent_t> ev(ring ? 0 : 2 * (size_t)n_epochs, nullptr);
     int rc = 0;
     for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) rc = fail(-2, "hipEventCreate failed");
     for (int ep = 0; ep < n_epochs && rc == 0; ++ep) {
+        if (ring) {
+            if (graphed) { if (hipGraphLaunch(gexec, stream) != hipSuccess) rc = fail(-2, "grouped epoch graph launch failed"); }
+            else issue_all(stream);
+            continue;
+        }
         (void)hipEventRecord(ev[2 * ep], stream);
         if (graphed) { if (hipGraphLaunch(gexec, stream) != hipSuccess) rc = fail(-2, "grouped epoch graph launch failed"); }
         else issue_all(stream);
@@ -1543,7 +1598,13 @@ int smrt_vae_train_epochs_multi(smrt_vae** hs, int32_t n_handles, const float* c
     if (rc == 0) {
         for (int ep = 0; ep < n_epochs; ++ep) {
             float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, ev[2 * ep], ev[2 * ep + 1]);
+            if (ring) {                                  // an epoch ends when its last handle's closing launch has stamped
+                unsigned long long t0 = 0, t1 = 0;
+                for (int k = 0; k < n_handles; ++k) {
+                    t0 = std::max(t0, hs[k]->time_pin[ep]); t1 = std::max(t1, hs[k]->time_pin[ep + 1]);
+                }
+                ms = (float)((double)(t1 - t0) * 1e-5);   // 100 MHz
+            } else (void)hipEventElapsedTime(&ms, ev[2 * ep], ev[2 * ep + 1]);
             if (epoch_ms_host) epoch_ms_host[ep] = ms;
             for (int k = 0; k < n_handles; ++k)
                 if (epoch_cost_host) epoch_cost_host[(size_t)k * n_epochs + ep] = hs[k]->cost_pin[ep];

@@ -695,12 +695,20 @@ __device__ __forceinline__ void finalize_body(const FinalizeArgs& a) {
         const float data = a.presummed ? a.presummed[0] : (bce + kl) * a.inv_batch;
         if (a.loss_sum_out) a.loss_sum_out[0] = data;
         if (a.cost_out) a.cost_out[0] = data + a.l2 * l2s;
+        if (a.ring_ctr) {                                // the epoch ends here: cost and time of epoch e, straight to the host
+            const unsigned e = a.ring_ctr[0];
+            a.ring_cost[e] = data + a.l2 * l2s;
+            a.ring_time[e + 1] = wall_clock64();
+            if (a.ring_err) a.ring_err[e] = a.err_src[0];
+            a.ring_ctr[0] = e + 1;
+        }
         if (a.advance) {
             a.st->step += 1;
             a.st->b1pow *= 0.9f;
             a.st->b2pow *= 0.999f;
         }
     }
+    if (a.zero192 && threadIdx.x < 192) a.zero192[threadIdx.x] = 0u;
 }
 
 __global__ __launch_bounds__(256) void finalize_kernel(const FinalizeArgs a) { finalize_body(a); }
@@ -710,6 +718,14 @@ __global__ __launch_bounds__(256) void finalize_multi(const MultiSlot<FinalizeAr
     finalize_body(s.a);
 }
 static MultiReg<FinalizeArgs> reg_finalize(finalize_kernel, finalize_multi);
+
+__global__ void ring_start_kernel(unsigned long long* ring_time, unsigned* ring_ctr, unsigned e0) {
+    ring_time[e0] = wall_clock64();
+    ring_ctr[0] = e0;
+}
+void launch_ring_start(hipStream_t s, unsigned long long* ring_time, unsigned* ring_ctr, unsigned e0) {
+    SMRT_LAUNCH(ring_start_kernel, dim3(1), dim3(1), 0, s, ring_time, ring_ctr, e0);
+}
 
 void launch_finalize(hipStream_t s, const FinalizeArgs& a) {
     SMRT_LAUNCH(finalize_kernel, dim3(1), dim3(256), 0, s, a);

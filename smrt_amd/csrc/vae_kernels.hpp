@@ -272,7 +272,15 @@ struct FinalizeArgs {
     float* loss_sum_out;             // optional: (bce+kl)*inv_batch without the L2 term
     DevState* st;
     int advance;                     // bump step / beta powers
+    // Epoch ring (api.hip: train_epochs without the persistent kernel), or null: the launch that closes an epoch also
+    // writes its cost and a 100 MHz time stamp into pinned host memory at the epoch's index, kept in device memory --
+    // an epoch graph then needs no copy node and no event pair around it.
+    float* ring_cost; unsigned long long* ring_time; unsigned* ring_ctr;
+    // ... after a persistent launch also the launch's error word (persist_body.hpp) into ring_err at the same index, and
+    // the 192 producer flags are cleared for the next launch (stream order: the persistent kernel has ended)
+    const unsigned* err_src; unsigned* ring_err; unsigned* zero192;
 };
+void launch_ring_start(hipStream_t s, unsigned long long* ring_time, unsigned* ring_ctr, unsigned e0);   // time[e0] = now, index = e0
 
 // Row-tile fused forward + backward (fused_small.hip)
 struct FusedLayer {       // host-side LDS plan of one dense layer

@@ -272,6 +272,64 @@ def test_grouped_class_fits_are_bit_identical_to_separate_fits(monkeypatch):
     np.testing.assert_allclose(eg[2].epoch_costs_, np.array(o.epoch_costs_), rtol=1e-4)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["layers", "fused", "persistent"])
+def test_epoch_ring_reports_the_same_costs_as_events_and_copies(monkeypatch, path):
+    """The launch that closes an epoch writes the epoch's cost and a time stamp (after a persistent launch also its error
+    word) straight into pinned host memory (the epoch ring, FinalizeArgs::ring_*; SMRT_HIP_EPOCH_RING=0: an event pair and
+    4-byte copies per epoch).  Both forms must report the same costs bit for bit and leave the same weights on every
+    training path (per-layer launches, the two-kernel step, the persistent kernel) -- one call, a second call with
+    more epochs (the ring is re-allocated, the cached epoch graph dropped), early stopping, the grouped fit of several
+    handles -- and the ring's epoch times must be positive and add up to no more than the call's wall time."""
+    import time
+    from smrt_amd import _hip
+    monkeypatch.setenv("SMRT_HIP_PERSIST", "1" if path == "persistent" else "0")
+    monkeypatch.setenv("SMRT_HIP_FUSED", "0" if path == "layers" else "1")
+    rs = np.random.RandomState(31)
+    D, hidden, Z, B = 64, [128], 16, 128
+    X = rs.uniform(0, 1, size=(500, D))
+
+    def mk(opt, lr, seed):
+        return _hip.VaeHandle(n_features=D, hidden=hidden, n_latent=Z, activation="sigmoid", optimizer=opt, learning_rate=lr,
+                              l2_penalty=1e-4, clip=True, gclip_min=-5.0, gclip_max=5.0, eps=1e-10, dropout=1.0, seed=seed,
+                              max_batch=B, device=0)
+
+    out = {}
+    for ring in ("1", "0"):
+        monkeypatch.setenv("SMRT_HIP_EPOCH_RING", ring)
+        h = mk("rms_prop", 0.01, 9)
+        c1, _ = h.train_epochs(X, B, 3)
+        t0 = time.perf_counter()
+        c2, ms2 = h.train_epochs(X, B, 40)
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        c3, _ = h.train_epochs(X[:300], B, 30, early_stopping=True, min_change=1.0)
+        assert len(c1) == 3 and len(c2) == 40 and 2 <= len(c3) < 30
+        assert (h.last_epoch_launches == 2) == (path == "persistent")
+        assert np.all(np.asarray(ms2) > 0.0) and float(np.sum(ms2)) <= wall_ms, (ms2, wall_ms)
+        out[ring] = (np.concatenate([c1, c2, c3]), h.get_params(), h.step_count)
+        h.close()
+    np.testing.assert_array_equal(out["1"][0], out["0"][0])
+    np.testing.assert_array_equal(out["1"][1], out["0"][1])
+    assert out["1"][2] == out["0"][2]
+    if path != "layers":
+        return                                           # (grouped fits are for nets off the LDS-resident path)
+    grouped = {}
+    for ring in ("1", "0"):
+        monkeypatch.setenv("SMRT_HIP_EPOCH_RING", ring)
+        hs = [mk("adam", 0.002, 9 + k) for k in range(3)]
+        Xs = [_hip.to_device_padded(x, hs[0].device) for x in (X[:500], X[:130], X[100:364])]
+        res = _hip.train_epochs_multi(hs, Xs, B, 4)
+        assert res is not None
+        costs, ms = res
+        assert np.all(np.asarray(ms) > 0.0)
+        grouped[ring] = (np.asarray(costs), [h.get_params() for h in hs])
+        for h in hs:
+            h.close()
+    np.testing.assert_array_equal(grouped["1"][0], grouped["0"][0])
+    for a, b in zip(grouped["1"][1], grouped["0"][1]):
+        np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("D,hidden,Z,B,act,opt", [(784, [450], 10, 128, "sigmoid", "rms_prop"),     # the reference's own net and batch
                                                   (203, [77, 45], 6, 83, "tanh", "adagrad"),       # ragged everything, two hidden layers
                                                   (90, [300], 16, 256, "relu", "sgd")])
