@@ -161,7 +161,22 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
 
     n_synth = sum(j[3] for j in jobs)
     n_total = n_orig + n_synth
-    synth = np.empty((n_synth, n_features), dtype=np.float32)      # what the kernels produce (fp32, autoencoder.py:517)
+    # what the kernels produce (fp32, autoencoder.py:517).  The slab is page-locked when a GPU fills it (torch's caching host
+    # allocator: free after the first call): the decoded rows of C3 are 502 MB of downloads on the critical path, 33 ms into
+    # pageable memory, 14 ms into pinned.  SMRT_PIN_SLAB_MB caps it (default 4096, 0: never).
+    synth = None
+    pinned = False
+    pin_cap = int(os.environ.get("SMRT_PIN_SLAB_MB", "4096")) << 20
+    if 0 < n_synth * n_features * 4 <= pin_cap:
+        import torch
+        if torch.cuda.is_available():
+            try:
+                synth = torch.empty((n_synth, n_features), dtype=torch.float32, pin_memory=True).numpy()
+                pinned = True
+            except RuntimeError:
+                synth = None
+    if synth is None:
+        synth = np.empty((n_synth, n_features), dtype=np.float32)
     y_out_codes = np.empty(n_total, dtype=y_codes.dtype)
     y_out_codes[:n_orig] = y_codes
 
@@ -207,7 +222,8 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
             group = pool.submit(fit_group, [fits[j] for j in fresh_jobs], [subs[j] for j in fresh_jobs], n_threads)
             fits = [None if f is None else _GroupMember(group, f) for f in fits]
 
-        synth.fill(0.0)                      # touch the slab's pages while the fits run, not while they are waited for
+        if not pinned:
+            synth.fill(0.0)                  # touch the slab's pages while the fits run, not while they are waited for
         # ---- the shared stream, in class order (smrt.py:226-238 via autoencoder.py:519-572)
         for j, (code, label, n_sub, need) in enumerate(jobs):
             mine = owners[j] == rank
@@ -250,6 +266,16 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
             # latent draws to the kernels' dtype (what feed_forward does, autoencoder.py:517), still under the cover of the fits
             drawn = [(None if nz is None else nz.astype(np.float32), si) for nz, si in drawn]
         lap("originals")
+        if pinned and n_fresh:
+            # A page-locked slab's first CPU touch is a fault into the driver per page (502 MB: 160 ms on one thread, 57 ms
+            # inside the threaded assembly): taken here, on several threads, while the GPU trains and the host has nothing
+            # else to do.  (A slab that torch's allocator hands out again is mapped already: 1-2 ms.)
+            from concurrent.futures import ThreadPoolExecutor as _TP
+            n_touch = max(1, min(8, (os.cpu_count() or 8), n_synth // 4096))
+            step = -(-n_synth // n_touch)
+            with _TP(max_workers=n_touch) as tp:
+                list(tp.map(lambda i: synth[i * step:(i + 1) * step].fill(0.0), range(n_touch)))
+            lap("touch")
 
         # ---- per-class generate for the fresh fits: decode what was drawn above
         for j, (code, label, n_sub, need) in enumerate(jobs):
