@@ -96,8 +96,10 @@ int  smrt_vae_train_step(smrt_vae* h, const float* X_dev, int64_t ldx, int32_t r
 
 /* The whole _train loop (base.py:198-245) on device: contiguous unshuffled batches with a ragged
  * tail, n_epochs passes, cost of the LAST batch per epoch, optional early stopping
- * |last - c| <= min_change.  One host sync per epoch.
- *   epoch_cost_host[n_epochs], epoch_ms_host[n_epochs] (hipEvent time per epoch), *epochs_done. */
+ * |last - c| <= min_change.  One host sync per call (one per epoch under early stopping).
+ *   epoch_cost_host[n_epochs], epoch_ms_host[n_epochs], *epochs_done.  Epoch times are device times: the launch that
+ *   closes an epoch writes its cost and a 100 MHz time stamp into pinned host memory (an epoch's time is the difference to
+ *   the previous stamp); with SMRT_HIP_EPOCH_RING=0 they are hipEvent pairs around each epoch and the cost is copied back. */
 int  smrt_vae_train_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64_t n_rows, int32_t batch_size,
                            int32_t n_epochs, int32_t early_stopping, float min_change,
                            float* epoch_cost_host, float* epoch_ms_host, int32_t* epochs_done);
