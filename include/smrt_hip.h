@@ -207,7 +207,8 @@ int  smrt_vae_profile_epochs(smrt_vae* h, const float* X_dev, int64_t ldx, int64
  *                          (smrt/autoencode/autoencoder.py:549-572, called per class from smrt/balance/smrt.py:226-238)
  *   smrt_rng_permutation = random_state.permutation(np.arange(n))  the output shuffle (smrt/balance/smrt.py:244)
  * State in / out in RandomState.get_state(legacy=True) form: key[624] (uint32), pos in [0, 624], has_gauss, cached_gauss.
- * All pointers are HOST memory.  Returns 0, or -1 on a bad argument (state untouched). */
+ * All pointers are HOST memory.  Returns 0, -1 on a bad argument or -2 when the work arrays cannot be allocated (state
+ * untouched either way).  The work arrays are kept per calling thread between calls (up to 256 MB). */
 int  smrt_rng_normal(uint32_t* key, int32_t* pos, int32_t* has_gauss, double* cached_gauss, double loc, double scale,
                      double* out, int64_t n, int32_t n_threads);
 int  smrt_rng_permutation(uint32_t* key, int32_t* pos, int64_t* out, int64_t n);

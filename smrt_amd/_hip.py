@@ -269,7 +269,7 @@ def rng_normal(rs, size, loc=0.0, scale=1.0, n_threads=None):
     rc = load().smrt_rng_normal(key.ctypes.data, C.byref(pos), C.byref(has), C.byref(cached), float(loc), float(scale),
                                 out.ctypes.data, n, int(n_threads))
     if rc != 0:
-        raise HipLibraryError("smrt_rng_normal rejected its arguments (%d)" % rc)
+        raise HipLibraryError("smrt_rng_normal failed (%d: -1 bad argument, -2 out of host memory)" % rc)
     rs.set_state(("MT19937", key, int(pos.value), int(has.value), float(cached.value)))
     return out.reshape(shape)
 
@@ -283,7 +283,7 @@ def rng_permutation(rs, n):
     out = np.empty(n, dtype=np.int64)
     rc = load().smrt_rng_permutation(key.ctypes.data, C.byref(pos), out.ctypes.data, n)
     if rc != 0:
-        raise HipLibraryError("smrt_rng_permutation rejected its arguments (%d)" % rc)
+        raise HipLibraryError("smrt_rng_permutation failed (%d: -1 bad argument, -2 out of host memory)" % rc)
     rs.set_state(("MT19937", key, int(pos.value), int(has.value), float(cached.value)))     # (a shuffle leaves the kept normal alone)
     return out
 

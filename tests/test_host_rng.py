@@ -67,3 +67,26 @@ def test_the_sequence_smrt_balance_draws():
     for x, y in zip(wa, wb):
         assert np.array_equal(x, y)
     assert _same_state(a, b)
+
+
+def test_work_arrays_are_reused_across_calls_of_other_sizes_and_threads():
+    """The work arrays of both entry points live per calling thread and only grow: calls of growing, shrinking and odd
+    sizes on one thread, and the same sequence on two other threads at once, must each stay numpy's stream bit for bit."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def sequence(seed):
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        for n_norm, n_perm in ((4097, 5000), (300001, 70000), (8193, 2), (65537, 250000), (4099, 4097)):
+            want = a.normal(size=n_norm)
+            got = _hip.rng_normal(b, n_norm)
+            if not np.array_equal(got.view(np.uint64), want.view(np.uint64)):
+                return False
+            if not np.array_equal(a.permutation(n_perm), _hip.rng_permutation(b, n_perm)):
+                return False
+            if not _same_state(a, b):
+                return False
+        return True
+
+    assert sequence(11)
+    with ThreadPoolExecutor(max_workers=2) as pool:
+        assert all(pool.map(sequence, (12, 13)))
