@@ -6,6 +6,8 @@ numpy views of the weights; the arithmetic itself lives in the HIP library.
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 
 from ..utils import get_random_state
@@ -42,24 +44,62 @@ def resolve_latent(n_latent_factors, n_features):
     raise TypeError("n_latent_factors must be an int or a float")
 
 
+_STREAM_LOCK = threading.Lock()
+_STREAM_CACHE = {}                    # (seed, layer_type) -> the longest unit stream drawn so far (one entry, <= 64 MB)
+_STREAM_CACHE_BYTES = 64 << 20
+
+
+def _unit_stream(seed, layer_type, n):
+    """First ``n`` values of ``RandomState(seed).random_sample`` (xavier) or ``.standard_normal`` (gaussian).
+
+    Every layer restarts the generator from the same seed (see ``initial_parameters``), so a layer's draws are a PREFIX
+    of the longest layer's, and ``uniform(-b, b)`` / ``normal(0, s)`` are ``-b + (2 b) u`` / ``0 + s g`` of those unit
+    draws in numpy's legacy generator (``loc + scale * x``, one multiply and one add in fp64).  Drawing the stream once
+    per net instead of once per layer -- and once for all the per-class nets of one ``smrt_balance`` call -- gives the same
+    bits (``tests/test_host_goldens.py``) for a seventh of the Mersenne-Twister work on a 4 x 1024 net."""
+    key = (int(seed) & 0xFFFFFFFF, layer_type)
+    with _STREAM_LOCK:
+        u = _STREAM_CACHE.get(key)
+        if u is not None and u.shape[0] >= n:
+            return u[:n]
+    rs = np.random.RandomState(key[0])
+    u = rs.random_sample(n) if layer_type == "xavier" else rs.standard_normal(n)
+    if u.nbytes <= _STREAM_CACHE_BYTES:
+        with _STREAM_LOCK:
+            _STREAM_CACHE.clear()
+            _STREAM_CACHE[key] = u
+    return u
+
+
 def initial_parameters(dims, layer_type, bias_strategy, seed):
     """Initial (W, b) per layer, fp32, ABI order.
 
     Xavier: U(+-sqrt(6/(fi+fo))) (layer.py:457-461); Gaussian: N(0, sqrt(2/fi)) (layer.py:412-414).
     The reference draws from TensorFlow's Philox stream with the SAME (graph, op) seed pair for every
     layer, so same-shaped layers (the two latent heads) start identical; that property is kept by
-    restarting ``RandomState(seed)`` per layer.  The values themselves are this package's own stream.
+    restarting ``RandomState(seed)`` per layer.  The values themselves are this package's own stream:
+    ``RandomState(seed).uniform(-bound, bound, (fi, fo))`` resp. ``.normal(0, sqrt(2/fi), (fi, fo))``, taken here
+    from one shared unit stream (``_unit_stream``).
     """
-    out = []
+    dims = [(int(fi), int(fo)) for fi, fo in dims]
+    u = _unit_stream(seed, layer_type, max([fi * fo for fi, fo in dims] + [0]))
+    out, by_shape = [], {}
     for fi, fo in dims:
-        rs = np.random.RandomState(int(seed) & 0xFFFFFFFF)
-        if layer_type == "xavier":
-            bound = np.sqrt(6.0 / (fi + fo))
-            W = rs.uniform(-bound, bound, size=(fi, fo))
+        W32 = by_shape.get((fi, fo))                                  # same shape = same draws, same scale: same values
+        if W32 is None:
+            W = np.empty(fi * fo)
+            if layer_type == "xavier":
+                bound = np.sqrt(6.0 / (fi + fo))
+                np.multiply(u[:fi * fo], bound - (-bound), out=W)     # == rs.uniform(-bound, bound, ...): low + (high - low) * u
+                W += -bound
+            else:
+                np.multiply(u[:fi * fo], (2.0 / fi) ** 0.5, out=W)    # == rs.normal(0, sigma, ...): loc + scale * gauss
+                W += 0.0
+            W32 = by_shape[(fi, fo)] = W.reshape(fi, fo).astype(np.float32)
         else:
-            W = rs.normal(0.0, (2.0 / fi) ** 0.5, size=(fi, fo))
+            W32 = W32.copy()
         b = np.zeros(fo) if bias_strategy == "zeros" else np.ones(fo)
-        out.append((W.astype(np.float32), b.astype(np.float32)))
+        out.append((W32, b.astype(np.float32)))
     return out
 
 

@@ -237,3 +237,45 @@ def test_small_integer_labels_of_any_integer_dtype(dtype):
     u, c = np.unique(y, return_counts=True)
     assert n_classes == 3 and np.array_equal(present, u) and np.array_equal(counts, c)
     assert majority == 0 and target == 20 and present.dtype == y.dtype
+
+
+@pytest.mark.parametrize("layer_type", ["xavier", "gaussian"])
+def test_initial_parameters_are_the_per_layer_numpy_draws_bit_for_bit(layer_type):
+    """``initial_parameters`` takes every layer from ONE shared unit stream (a layer's draws are a prefix of the longest
+    layer's, same-shaped layers are computed once): the values must be those of the per-layer definition --
+    ``RandomState(seed).uniform(-b, b, (fi, fo))`` / ``.normal(0, sqrt(2 / fi), (fi, fo))`` -- bit for bit, for cached
+    and uncached streams, from several threads, and every layer must own its array."""
+    from concurrent.futures import ThreadPoolExecutor
+    from smrt_amd.autoencode import topography
+
+    def direct(dims, seed):
+        out = []
+        for fi, fo in dims:
+            rs = np.random.RandomState(int(seed) & 0xFFFFFFFF)
+            if layer_type == "xavier":
+                bound = np.sqrt(6.0 / (fi + fo))
+                W = rs.uniform(-bound, bound, size=(fi, fo))
+            else:
+                W = rs.normal(0.0, (2.0 / fi) ** 0.5, size=(fi, fo))
+            out.append(W.astype(np.float32))
+        return out
+
+    nets = ([(784, 450), (450, 10), (450, 10), (10, 450), (450, 784)],            # N1: the heads share their values
+            [(64, 128), (128, 16), (128, 16), (16, 128), (128, 64)],
+            [(7, 3), (3, 2), (3, 2), (2, 3), (3, 7)],
+            [(5, 5), (5, 5), (5, 5)],
+            [(40, 300), (300, 300), (300, 300), (300, 9), (300, 9), (9, 300), (300, 300), (300, 40)])
+
+    def check(args):
+        dims, seed = args
+        got = topography.initial_parameters(dims, layer_type, "ones", seed)
+        want = direct(dims, seed)
+        ok = all(w.dtype == np.float32 and np.array_equal(w.view(np.uint32), v.view(np.uint32)) and np.all(b == 1.0)
+                 for (w, b), v in zip(got, want))
+        return ok and len({id(w) for w, _ in got}) == len(got)
+
+    cases = [(dims, seed) for seed in (42, 0, (1 << 32) + 5) for dims in nets]
+    topography._STREAM_CACHE.clear()
+    assert all(check(c) for c in cases)                  # growing and shrinking streams, cache hits and misses
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        assert all(pool.map(check, cases * 2))
