@@ -53,8 +53,11 @@ def fit_group(estimators, Xs, n_threads=8):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=max(1, min(int(n_threads), len(estimators)))) as pool:
         prepared = list(pool.map(lambda ex: ex[0]._prepare_fit(ex[1]), zip(estimators, Xs)))
+        t_mid = time.perf_counter()
         X_devs = list(pool.map(lambda ex: _hip.to_device_padded(ex[1][0], ex[0].sess.device), zip(estimators, prepared)))
     t1 = time.perf_counter()
+    if timing:
+        sys.stderr.write("[fit_group] sessions + initial weights %.1f ms, uploads %.1f ms\n" % (1e3 * (t_mid - t0), 1e3 * (t1 - t_mid)))
     res = _hip.train_epochs_multi([e.sess for e in estimators], X_devs, prepared[0][2], int(first.n_epochs))
     if timing:
         sys.stderr.write("[fit_group] prepare %.1f ms, train %.1f ms (%s)\n" % (
