@@ -230,6 +230,14 @@ int  smrt_assemble_rows_part(const void* X, int32_t x_is_f32, int64_t n_orig, in
                              const float* synth, int64_t n_synth, int64_t ld_synth,
                              const int64_t* order, int64_t n_out, double* out, int32_t n_threads, int32_t which);
 
+/* The synthetic half in pieces (no counterpart in the reference): writes only the output rows whose source is one of the
+ * synthetic rows [s_lo, s_hi) of synth [n_synth][ld_synth]; order / n_out / out as above (order entries are trusted: run
+ * smrt_assemble_rows_part with which = 1 over the same order first, it validates them).  smrt_balance calls it per class,
+ * while the next class's rows are still being decoded and downloaded. */
+int  smrt_assemble_rows_synth_range(const float* synth, int64_t n_orig, int64_t n_synth, int64_t ld_synth, int64_t d,
+                                    const int64_t* order, int64_t n_out, double* out, int32_t n_threads,
+                                    int64_t s_lo, int64_t s_hi);
+
 /* The finiteness sweep of sklearn's check_array (smrt/balance/base.py:24) on n_threads cores: 1 when all n elements of
  * the fp32 / fp64 HOST array are finite, 0 otherwise (the caller then lets sklearn raise its own error), -1 on a bad
  * argument. */

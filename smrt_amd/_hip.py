@@ -28,7 +28,7 @@ EXPORTS = [
     "smrt_vae_grad_step", "smrt_vae_apply_grads", "smrt_vae_grad_step_async", "smrt_vae_apply_grads_async",
     "smrt_vae_set_stream", "smrt_vae_encode", "smrt_vae_decode",
     "smrt_vae_generate", "smrt_vae_generate_noalloc", "smrt_vae_generate_noalloc_max_rows", "smrt_vae_sample_eps", "smrt_vae_last_epoch_launches", "smrt_vae_profile_epochs",
-    "smrt_assemble_rows", "smrt_assemble_rows_part", "smrt_assemble_rows_f64", "smrt_all_finite", "smrt_rng_normal", "smrt_rng_permutation", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_mfma_peak_16x16x4", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
+    "smrt_assemble_rows", "smrt_assemble_rows_part", "smrt_assemble_rows_synth_range", "smrt_assemble_rows_f64", "smrt_all_finite", "smrt_rng_normal", "smrt_rng_permutation", "smrt_knn_f64", "smrt_smote_rows_f64", "smrt_diag_mfma_peak", "smrt_diag_mfma_peak_16x16x4", "smrt_diag_hbm_bandwidth", "smrt_diag_step_floor",
     "smrt_last_error", "smrt_version",
 ]
 
@@ -111,6 +111,7 @@ def load():
     lib.smrt_assemble_rows_f64.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32]
     lib.smrt_all_finite.argtypes = [vp, i32, i64, i32]
     lib.smrt_assemble_rows_part.argtypes = [vp, i32, i64, i64, i64, vp, i64, i64, vp, i64, vp, i32, i32]
+    lib.smrt_assemble_rows_synth_range.argtypes = [vp, i64, i64, i64, i64, vp, i64, vp, i32, i64, i64]
     lib.smrt_rng_normal.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_double), C.c_double, C.c_double, vp, i64, i32]
     lib.smrt_rng_permutation.argtypes = [vp, C.POINTER(i32), vp, i64]
     _lib = lib
@@ -317,12 +318,49 @@ class SplitAssembly(object):
     def originals(self):
         self._run(None, 1)
 
-    def synthetic(self, synth):
-        synth = np.ascontiguousarray(synth, dtype=np.float32)
+    def _check_synth(self, synth):
+        if synth.dtype != np.float32 or not synth.flags.c_contiguous:
+            synth = np.ascontiguousarray(synth, dtype=np.float32)
         if synth.shape != (self.n_synth, self.X.shape[1]):
             raise ValueError("expected %r synthetic rows, got %r" % ((self.n_synth, self.X.shape[1]), synth.shape))
+        return synth
+
+    def synthetic(self, synth):
+        synth = self._check_synth(synth)
+        self.wait()
         if self.n_synth:
             self._run(synth, 2)
+        return self.out
+
+    def synthetic_range_async(self, synth, lo, hi):
+        """Start writing the output rows whose source is one of the synthetic rows ``[lo, hi)`` of the slab ``synth`` (the
+        slab itself, not a copy: it must stay alive and those rows must be final) on a background thread; ``wait()``
+        joins everything started so far.  ``originals()`` must have run (it validates ``order``)."""
+        synth = self._check_synth(synth)
+        if getattr(self, "_bg", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._bg, self._pending = ThreadPoolExecutor(max_workers=1), []
+        n, d = self.X.shape
+
+        def job():
+            rc = self._lib.smrt_assemble_rows_synth_range(
+                synth.ctypes.data, n, self.n_synth, d, d, self.order.ctypes.data if self.order is not None else None,
+                self.n_out, self.out.ctypes.data, self.n_threads, int(lo), int(hi))
+            if rc != 0:
+                raise HipLibraryError("smrt_assemble_rows_synth_range rejected its arguments (%d)" % rc)
+
+        self._pending.append(self._bg.submit(job))
+
+    def wait(self):
+        """Join the ranges started by ``synthetic_range_async`` (re-raises their errors); returns ``out``."""
+        bg = getattr(self, "_bg", None)
+        if bg is not None:
+            try:
+                for f in self._pending:
+                    f.result()
+            finally:
+                bg.shutdown(wait=True)
+                self._bg, self._pending = None, []
         return self.out
 
 

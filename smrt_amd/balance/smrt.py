@@ -218,6 +218,8 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
     lap("split")
 
     blocks, cursor, drawn = [], 0, []
+    assembled = set()                        # jobs whose synthetic rows are in the output already (synthetic_range_async)
+    assembly = None
     dev_rows = dict()                        # job -> decoded rows still in HBM (sent from there under RCCL)
     try:
         if n_fresh:
@@ -298,11 +300,23 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
                 torch.from_numpy(synth[start:start + need]).copy_(rows_dev)
                 if world > 1 and tuple(rows_dev.shape) == (need, n_features):
                     dev_rows[j] = rows_dev
+                if world == 1 and len(jobs) > 1:
+                    # their place in the output while the next class is decoded and downloaded (the download is a DMA into
+                    # page-locked memory: the host's cores are free for this)
+                    assembly.synthetic_range_async(synth, start, start + need)
+                    assembled.add(j)
             else:
                 z_mu, log_sigma = encoder.encode(subs[j][sample_idcs, :])         # == generate_from_sample(...)
                 z_mu += noise * np.exp(log_sigma)
                 synth[start:start + need] = np.asarray(encoder.feed_forward(z_mu))
             drawn[j] = None
+    except BaseException:
+        if assembly is not None:
+            try:
+                assembly.wait()              # no background writer may outlive the slab
+            except Exception:                # noqa: BLE001  (the first error is the one to report)
+                pass
+        raise
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
@@ -316,7 +330,11 @@ def smrt_balance(X, y, n_hidden, n_latent_factors, return_estimators=False, bala
 
     if shuffle:
         y_out = y_out[output_order]
-    X_out = assembly.synthetic(synth)                     # the other rows of fp64 [X ; synthetic][order]
+    if assembled and len(assembled) == len(jobs):
+        X_out = assembly.wait()                           # every class's rows went in behind its download
+    else:
+        assembly.wait()
+        X_out = assembly.synthetic(synth)                 # the other rows of fp64 [X ; synthetic][order]
     lap("assemble")
 
     if return_estimators:

@@ -89,6 +89,37 @@ extern "C" int smrt_assemble_rows_part(const void* X, int32_t x_is_f32, int64_t 
     return assemble<float>(X, x_is_f32, n_orig, d, ldx, synth, n_synth, ld_synth, order, n_out, out, n_threads, which);
 }
 
+// The synthetic half in pieces (no counterpart in the reference): only the output rows whose source is one of the synthetic
+// rows [s_lo, s_hi) -- smrt_balance writes a class's rows while the next class's are still being decoded and downloaded.
+extern "C" int smrt_assemble_rows_synth_range(const float* synth, int64_t n_orig, int64_t n_synth, int64_t ld_synth, int64_t d,
+                                              const int64_t* order, int64_t n_out, double* out, int32_t n_threads,
+                                              int64_t s_lo, int64_t s_hi) {
+    if (!synth || !out || n_orig < 0 || n_synth < 0 || d < 1 || ld_synth < d || n_out < 0) return -1;
+    if (s_lo < 0 || s_hi < s_lo || s_hi > n_synth) return -1;
+    if (!order && n_out != n_orig + n_synth) return -1;
+    if (s_lo == s_hi) return 0;
+    const int64_t r_lo = n_orig + s_lo, r_hi = n_orig + s_hi;
+    // without an order the rows are where they are in the concatenation; with one, every thread scans its share of it
+    const int64_t i_lo = order ? 0 : r_lo, i_hi = order ? n_out : r_hi;
+    auto run = [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const int64_t r = order ? order[i] : i;
+            if (r >= r_lo && r < r_hi) put_row<float>(synth + (r - n_orig) * ld_synth, out + i * d, d);
+        }
+    };
+    const int64_t n = i_hi - i_lo, min_rows = order ? 16384 : 4096;
+    const int nt = std::max(1, (int)std::min<int64_t>(n_threads, (n + min_rows - 1) / min_rows));
+    if (nt == 1) { run(i_lo, i_hi); return 0; }
+    std::vector<std::thread> pool;
+    const int64_t per = (n + nt - 1) / nt;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t lo = i_lo + t * per, hi = std::min<int64_t>(i_hi, lo + per);
+        if (lo < hi) pool.emplace_back(run, lo, hi);
+    }
+    for (auto& th : pool) th.join();
+    return 0;
+}
+
 namespace {
 // An IEEE value is NaN or infinite exactly when its exponent field is all ones: the largest |bit pattern| of a range says
 // whether any element is.  Integer max over the words vectorises (AVX2 clone picked at load time where the CPU has it).

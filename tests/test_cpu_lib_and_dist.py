@@ -147,6 +147,28 @@ def test_assemble_rows_matches_numpy():
         assert np.array_equal(sa.synthetic(S[:, :3]), ref)
     with pytest.raises(ValueError):
         _hip.SplitAssembly(big, 37, None).synthetic(S[:5, :3])
+    # the synthetic half in pieces on the background thread (smrt_balance: a class's rows go in while the next class's are
+    # downloaded): each piece touches only its rows, together they are the one-pass result; many rows, several threads
+    S3 = np.ascontiguousarray(rs.uniform(size=(30011, 3)).astype(np.float32))
+    order_big = rs.permutation(50011)
+    for order_ in (order_big, None):
+        sa = _hip.SplitAssembly(big, 30011, order_, n_threads=5)
+        sa.out[:] = -7.0
+        sa.originals()
+        ref = np.vstack([big.astype(np.float64), S3.astype(np.float64)])
+        ref = ref if order_ is None else ref[order_]
+        src = np.arange(50011) if order_ is None else order_
+        sa.synthetic_range_async(S3, 100, 20000)
+        assert sa.wait() is sa.out
+        mine = (src >= 20100) & (src < 40000)
+        assert np.array_equal(sa.out[mine], ref[mine]) and np.all(sa.out[(src >= 20000) & ~mine] == -7.0)
+        for lo, hi in ((0, 100), (20000, 20000), (20000, 30011)):
+            sa.synthetic_range_async(S3, lo, hi)
+        assert np.array_equal(sa.wait(), ref)
+        with pytest.raises(_hip.HipLibraryError):
+            sa.synthetic_range_async(S3, 5, 30012)
+            sa.wait()
+        assert np.array_equal(sa.synthetic(S3), ref)
 
 
 def test_all_finite_sweep_and_validation_error_text():
